@@ -1,0 +1,88 @@
+"""ctypes binding of ``libotter_hip.so`` (the C ABI declared in ``include/otter_hip.h``).
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libotter_hip.so")
+
+ABI_VERSION = 1
+
+# epilogue word (mirrors include/otter_hip.h)
+ACT_NONE, ACT_QUICKGELU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
+OUT_F32 = 4
+RESIDUAL = 8
+
+
+class OtterHipError(RuntimeError):
+    pass
+
+
+class ReadoutBlock(Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "q_ln_w", "q_ln_b", "wq_t", "bq", "wo_t", "bo", "ln_w", "ln_b", "fc1_t", "fc1_b", "fc2_t", "fc2_b")]
+
+
+_P, _I, _L, _F = c_void_p, c_int, c_long, c_float
+
+_SIGNATURES = {
+    "otter_gemm_bf16": [_P, _L, _P, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "otter_layernorm": [_P, _L, _P, _P, _P, _L, _I, _I, _F, _I, _P],
+    "otter_vit_embed_lnpre": [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P],
+    "otter_text_embed": [_P, _I, _I, _P, _I, _P, _P, _L, _I, _I, _P],
+    "otter_im2col_patches": [_P, _I, _P, _I, _I, _I, _I, POINTER(c_float), POINTER(c_float), _P],
+    "otter_attn_fwd_d64": [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "otter_attn_policy": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "otter_text_aware_pool_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "otter_pos_emb_transpose": [_P, _P, _I, _I, _P],
+    "otter_readout_pool_fwd": [POINTER(ReadoutBlock), _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "otter_l2norm_rows": [_P, _L, _P, _L, _I, _I, _P],
+    "otter_linear_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "otter_cast_bf16": [_P, _L, _P, _L, _I, _I, _I, _I, _P, _I, _P],
+    "otter_repeat_rows": [_P, _L, _P, _L, _I, _I, _I, _P],
+    "otter_add_pe": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "otter_window_append": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise loudly when it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OtterHipError(
+            f"{LIB_PATH} not found: build it with `make -C otter_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU or PyTorch fallback for the device path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.otter_last_error.restype = c_char_p
+    lib.otter_last_error.argtypes = []
+    lib.otter_hip_abi_version.restype = c_int
+    lib.otter_hip_abi_version.argtypes = []
+    got = lib.otter_hip_abi_version()
+    if got != ABI_VERSION:
+        raise OtterHipError(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}; rebuild the library")
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise OtterHipError(f"{name} failed (code {rc}): {lib.otter_last_error().decode()}")
+
+
+def exported_names():
+    return sorted(list(_SIGNATURES) + ["otter_last_error", "otter_hip_abi_version"])

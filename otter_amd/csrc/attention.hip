@@ -1,0 +1,243 @@
+// Fused multi-head attention for the CLIP towers (head_dim 64) and the policy transformer.
+//
+// CLIP kernel (attn_d64): one workgroup (4 waves) per (sequence, head).  The sequence is short (257 vision
+// tokens, <= 77 text tokens), so K and V of the head are staged once into LDS and each wave owns 16-query
+// tiles; the whole score row of a tile lives in registers, i.e. a plain (not online) softmax.
+//   * S^T = K . Q^T with v_mfma_f32_16x16x32_bf16 (keys on the accumulator rows, queries on the lanes), so
+//     every lane owns ONE query: the softmax reductions are per-lane loops plus two cross-lane steps.
+//   * In that orientation the accumulator registers are already the B operand of the second product
+//     O^T = V^T . P^T (k order permuted: slot j of lane group g is key 32s + 16(j>>2) + 4g + (j&3)), so P never
+//     leaves registers.  V is read from its row-major LDS image with ds_read_b64_tr_b16 (hardware transpose),
+//     addressed with the same key permutation.
+//   * LDS images are XOR-swizzled by 16-byte chunk: K for ds_read_b128 fragment reads, V for the transposed reads.
+// Policy kernel (attn_policy): head_dim 96, at most 32 keys; one wave per (episode, head, query), fp32.
+#include "common.hpp"
+#include "otter_hip.h"
+
+namespace {
+
+struct AttnArgs {
+    const __bf16* qkv; long ld;      // rows (seq*L + t), q|k|v blocks of heads*64 each
+    __bf16* out; long ldo;
+    int L, heads, causal;
+    float scale;
+};
+
+__device__ __forceinline__ int k_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int v_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }
+
+template <int NKT>   // NKT = number of 16-key tiles the registers hold (even)
+__global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LK = NKT * 16;
+    char* sK = smem;
+    char* sV = smem + LK * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seq = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+    const int L = p.L;
+    const long row0 = (long)seq * L;
+    const int hd = p.heads * 64;
+
+    // ---- stage K and V of this head (rows >= L are zero) ----
+    for (int idx = tid; idx < LK * 8; idx += 256) {
+        const int r = idx >> 3, c = idx & 7;
+        bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < L) {
+            const __bf16* base = p.qkv + (row0 + r) * p.ld + h * 64 + c * 8;
+            kv = *(const bf16x8*)(base + hd);
+            vv = *(const bf16x8*)(base + 2 * hd);
+        }
+        *(bf16x8*)(sK + r * 128 + (k_swz(r, c) << 4)) = kv;
+        *(bf16x8*)(sV + r * 128 + (v_swz(r, c) << 4)) = vv;
+    }
+    __syncthreads();
+
+    const int g = lane >> 4, li = lane & 15;
+    const int nkt = (L + 15) >> 4;                 // key tiles that hold real keys
+    const int nqt = nkt;
+    // K fragment read: row kt*16 + li, logical chunk ks*4 + g
+    const int k_row_off = li * 128;
+    const int k_sw = (li >> 1) & 7;
+    // V transposed read: lane li of group g addresses row r0 + (li>>2), bytes (li&3)*8 of the d-tile
+    const int vr = li >> 2;
+
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + li;                // this lane's query
+        const int qc = min(q, L - 1);
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *(const bf16x8*)(p.qkv + (row0 + qc) * p.ld + h * 64 + ks * 32 + g * 8);
+
+        // Every one of the NKT key tiles is computed, also those past L (their K rows are zero in LDS and the
+        // mask below removes them): a wave-uniform skip here would put a branch between an MFMA and the first
+        // read of its accumulator.
+        f32x4 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(sK + kt * 2048 + k_row_off + (((ks * 4 + g) ^ k_sw) << 4));
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+        // ---- mask + softmax over keys (per lane: one query) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + g * 4 + r;
+                const bool ok = (key < L) && (!p.causal || key <= q);
+                const float v = ok ? s[kt][r] * p.scale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[kt][r] - mx);     // exp(-inf) = 0 for masked keys
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        // ---- O^T = V^T . P^T ----
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < NKT / 2; ++s2) {
+            {
+                bf16x8 pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = f32_to_bf16(s[2 * s2][r]);
+                    pf[4 + r] = f32_to_bf16(s[2 * s2 + 1][r]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int rlo = 32 * s2 + 4 * g + vr, rhi = rlo + 16;
+                    const int cl = dt * 2 + ((li & 3) >> 1), sub = (li & 1) * 8;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sV + rlo * 128 + (v_swz(rlo, cl) << 4) + sub));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sV + rhi * 128 + (v_swz(rhi, cl) << 4) + sub));
+                    union { struct { s16x4 a, b; } h; bf16x8 v; } u;
+                    u.h.a = lo; u.h.b = hi;
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (q < L) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x4 ob;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(o[dt][r] * inv);
+                *(bf16x4*)(p.out + (row0 + q) * p.ldo + h * 64 + dt * 16 + g * 4) = ob;
+            }
+        }
+    }
+}
+
+template <int NKT>
+int launch_d64(const AttnArgs& a, int n_seq, hipStream_t s) {
+    constexpr int lds = NKT * 16 * 128 * 2;
+    auto kern = attn_d64<NKT>;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_seq * a.heads), dim3(256), lds, s, a);
+    OTTER_CHECK_LAUNCH("otter_attn_fwd_d64");
+    return OTTER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Policy attention: fp32 q|k|v rows of width 3*dim (dim = heads*hd), causal, window of at most 64 keys.
+// One wave per (episode b, head h, query i).  Query i of the call sits at window position pos0 + i and
+// attends keys 0 .. pos0+i of the same episode's rows (the rows double as the GPU-resident K/V history).
+struct PolicyAttnArgs {
+    const float* qkv; long ld;      // row (b*S + t)
+    __bf16* out; long ldo;          // row (b*Tq + i)
+    int S, Tq, pos0, heads, hd;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void attn_policy(PolicyAttnArgs p, int total) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= total) return;
+    const int i = w % p.Tq, h = (w / p.Tq) % p.heads, b = w / (p.Tq * p.heads);
+    const int dim = p.heads * p.hd;
+    const int qpos = p.pos0 + i, nkeys = qpos + 1;
+    const float* qrow = p.qkv + ((long)b * p.S + qpos) * p.ld + h * p.hd;
+    float sc = -INFINITY;
+    if (lane < nkeys) {
+        const float* krow = p.qkv + ((long)b * p.S + lane) * p.ld + dim + h * p.hd;
+        float acc = 0.f;
+        for (int d = 0; d < p.hd; d += 4) {
+            const f32x4 a = *(const f32x4*)(qrow + d), k = *(const f32x4*)(krow + d);
+            acc += a[0] * k[0] + a[1] * k[1] + a[2] * k[2] + a[3] * k[3];
+        }
+        sc = acc * p.scale;
+    }
+    const float mx = wave_max(sc);
+    const float e = (lane < nkeys) ? __expf(sc - mx) : 0.f;
+    const float inv = 1.0f / wave_sum(e);
+    for (int d = lane; d < p.hd; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < nkeys; ++j) {
+            const float pj = __shfl(e, j, 64);
+            acc += pj * p.qkv[((long)b * p.S + j) * p.ld + 2 * dim + h * p.hd + d];
+        }
+        p.out[((long)b * p.Tq + i) * p.ldo + h * p.hd + d] = f32_to_bf16(acc * inv);
+    }
+}
+
+}  // namespace
+
+extern "C" int otter_attn_fwd_d64(const void* qkv, long ld, void* out, long ldo, int n_seq, int L, int heads,
+                                  int causal, void* stream) {
+    OTTER_REQUIRE(qkv && out, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_fwd_d64: null operand");
+    if (n_seq == 0) return OTTER_OK;
+    OTTER_REQUIRE(n_seq > 0 && L > 0 && heads > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_fwd_d64: n_seq=%d L=%d heads=%d", n_seq, L, heads);
+    OTTER_REQUIRE(L <= 288, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_attn_fwd_d64: L=%d exceeds 288 keys", L);
+    OTTER_REQUIRE(ld >= 3 * heads * 64 && ld % 8 == 0 && ldo >= heads * 64 && ldo % 4 == 0, OTTER_ERR_ALIGNMENT,
+                  "otter_attn_fwd_d64: ld=%ld / ldo=%ld too small or misaligned for %d heads", ld, ldo, heads);
+    OTTER_REQUIRE(aligned16(qkv) && aligned16(out), OTTER_ERR_ALIGNMENT, "otter_attn_fwd_d64: operands must be 16-byte aligned");
+    OTTER_REQUIRE((long)n_seq * heads < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_attn_fwd_d64: grid too large");
+    AttnArgs a{(const __bf16*)qkv, ld, (__bf16*)out, ldo, L, heads, causal ? 1 : 0, 0.125f};
+    hipStream_t s = (hipStream_t)stream;
+    if (L <= 32) return launch_d64<2>(a, n_seq, s);
+    if (L <= 96) return launch_d64<6>(a, n_seq, s);
+    return launch_d64<18>(a, n_seq, s);
+}
+
+extern "C" int otter_attn_policy(const float* qkv, long ld, void* out, long ldo, int batch, int window, int n_query,
+                                 int pos0, int heads, int head_dim, void* stream) {
+    OTTER_REQUIRE(qkv && out, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_policy: null operand");
+    if (batch == 0 || n_query == 0) return OTTER_OK;
+    OTTER_REQUIRE(batch > 0 && n_query > 0 && pos0 >= 0 && heads > 0 && head_dim > 0, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_attn_policy: bad sizes");
+    OTTER_REQUIRE(pos0 + n_query <= window && window <= 64, OTTER_ERR_UNSUPPORTED_SHAPE,
+                  "otter_attn_policy: pos0+n_query=%d must fit the window=%d (<= 64)", pos0 + n_query, window);
+    OTTER_REQUIRE(head_dim % 4 == 0 && ld >= 3L * heads * head_dim && ld % 4 == 0 && ldo >= (long)heads * head_dim,
+                  OTTER_ERR_ALIGNMENT, "otter_attn_policy: head_dim must be a multiple of 4 and ld/ldo large enough");
+    OTTER_REQUIRE(aligned16(qkv), OTTER_ERR_ALIGNMENT, "otter_attn_policy: qkv must be 16-byte aligned");
+    PolicyAttnArgs a{qkv, ld, (__bf16*)out, ldo, window, n_query, pos0, heads, head_dim, 1.0f / sqrtf((float)head_dim)};
+    const long total = (long)batch * heads * n_query;
+    OTTER_REQUIRE(total < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_attn_policy: grid too large");
+    hipLaunchKernelGGL(attn_policy, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, (int)total);
+    OTTER_CHECK_LAUNCH("otter_attn_policy");
+    return OTTER_OK;
+}

@@ -1,0 +1,77 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the OTTER hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+static constexpr int kWave = 64;   // CDNA wavefront width
+
+// ---- error plumbing across the C ABI (no exceptions cross it) -------------------------------
+enum OtterStatus {
+    OTTER_OK = 0,
+    OTTER_ERR_INVALID_ARGUMENT = 1,
+    OTTER_ERR_UNSUPPORTED_SHAPE = 2,
+    OTTER_ERR_LAUNCH = 3,
+    OTTER_ERR_ALIGNMENT = 4,
+};
+
+void otter_set_error(const char* fmt, ...);   // defined in capi.hip (thread-local message)
+
+#define OTTER_REQUIRE(cond, code, ...)                 \
+    do {                                               \
+        if (!(cond)) {                                 \
+            otter_set_error(__VA_ARGS__);              \
+            return (code);                             \
+        }                                              \
+    } while (0)
+
+#define OTTER_CHECK_LAUNCH(name)                                                    \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            otter_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return OTTER_ERR_LAUNCH;                                                \
+        }                                                                           \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
+__device__ __forceinline__ __bf16 f32_to_bf16(float v) { return (__bf16)v; }   // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Bijective remap of a linear workgroup id so that each of the 8 XCDs (which receive workgroups
+// round-robin) works on one contiguous chunk of the tile space and its private L2 sees neighbouring tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    if (nwg < nx) return bid;
+    int q = nwg / nx, r = nwg % nx;
+    int xcd = bid % nx, idx = bid / nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,162 @@
+// Row-wise LayerNorm kernels (memory-bound): one 64-lane wave per row, the row held in registers,
+// 16-byte loads/stores, two-pass mean/variance in fp32 (matches torch.nn.LayerNorm numerics),
+// output bf16 (the next GEMM's A operand) or fp32 (the residual stream).
+//
+// Three row sources share the kernel:
+//   SRC_PLAIN   x[row]                                   (ln_1 / ln_2 / ln_post / ln_final / policy LNs)
+//   SRC_VIT     row t of image i = (t == 0 ? class_embedding : patch_tok[i*P + t-1]) + pos[t]   (-> ln_pre)
+//   SRC_TEXT    token_embedding[ids[b*ctx + t]] + pos[t]  (text tower input; no normalisation, fp32 out)
+#include "common.hpp"
+#include "otter_hip.h"
+
+namespace {
+
+enum { SRC_PLAIN = 0, SRC_VIT = 1, SRC_TEXT = 2 };
+
+struct LnArgs {
+    const float* x; long ldx;
+    const float* gamma; const float* beta;
+    void* y; long ldy;
+    int rows, width; float eps;
+    // SRC_VIT
+    const float* cls; const float* pos; int tokens;      // tokens = P + 1
+    // SRC_TEXT
+    const int* ids; int ctx, take, vocab;                 // row = b*take + t reads ids[b*ctx + t]
+};
+
+template <int NV, int SRC, bool OUT_F32, bool NORMALISE>
+__global__ __launch_bounds__(256) void ln_rows(LnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int nvec = p.width >> 2;
+
+    const float* src;
+    const float* add = nullptr;
+    if (SRC == SRC_PLAIN) {
+        src = p.x + (long)row * p.ldx;
+    } else if (SRC == SRC_VIT) {
+        const int img = row / p.tokens, t = row % p.tokens;
+        src = (t == 0) ? p.cls : p.x + ((long)img * (p.tokens - 1) + (t - 1)) * p.ldx;
+        add = p.pos + (long)t * p.width;
+    } else {
+        const int b = row / p.take, t = row % p.take;
+        const int id = min(max(p.ids[(long)b * p.ctx + t], 0), p.vocab - 1);   // never index outside the table
+        src = p.x + (long)id * p.ldx;
+        add = p.pos + (long)t * p.width;
+    }
+
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 64 + lane;
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (idx < nvec) {
+            v[i] = *(const f32x4*)(src + idx * 4);
+            if (SRC != SRC_PLAIN) v[i] += *(const f32x4*)(add + idx * 4);
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (NORMALISE) {
+        mean = wave_sum(sum) / (float)p.width;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 64 + lane;
+            if (idx < nvec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float d = v[i][e] - mean; sq += d * d; }
+            }
+        }
+        rstd = rsqrtf(wave_sum(sq) / (float)p.width + p.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx >= nvec) continue;
+        f32x4 o = v[i];
+        if (NORMALISE) {
+            o = (v[i] - mean) * rstd;
+            if (p.gamma) o = o * *(const f32x4*)(p.gamma + idx * 4) + *(const f32x4*)(p.beta + idx * 4);
+        }
+        if (OUT_F32) {
+            *(f32x4*)((float*)p.y + (long)row * p.ldy + idx * 4) = o;
+        } else {
+            bf16x4 ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = f32_to_bf16(o[e]);
+            *(bf16x4*)((__bf16*)p.y + (long)row * p.ldy + idx * 4) = ob;
+        }
+    }
+}
+
+template <int SRC, bool OUT_F32, bool NORMALISE>
+int launch_ln(const LnArgs& a, hipStream_t s, const char* name) {
+    const int grid = (a.rows + 3) / 4;
+    if (a.width <= 1024) hipLaunchKernelGGL((ln_rows<4, SRC, OUT_F32, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_rows<16, SRC, OUT_F32, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
+    OTTER_CHECK_LAUNCH(name);
+    return OTTER_OK;
+}
+
+int check_width(int width, const char* name) {
+    OTTER_REQUIRE(width > 0 && width % 4 == 0 && width <= 4096, OTTER_ERR_UNSUPPORTED_SHAPE,
+                  "%s: width=%d must be a multiple of 4 and <= 4096", name, width);
+    return OTTER_OK;
+}
+
+}  // namespace
+
+extern "C" int otter_layernorm(const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                               int rows, int width, float eps, int out_f32, void* stream) {
+    OTTER_REQUIRE(x && y && ((gamma == nullptr) == (beta == nullptr)), OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_layernorm: null operand (gamma and beta must both be given or both be NULL)");
+    if (rows == 0) return OTTER_OK;
+    OTTER_REQUIRE(rows > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_layernorm: rows=%d", rows);
+    if (int rc = check_width(width, "otter_layernorm")) return rc;
+    OTTER_REQUIRE(ldx >= width && ldx % 4 == 0 && ldy >= width && ldy % 4 == 0, OTTER_ERR_ALIGNMENT,
+                  "otter_layernorm: leading dimensions must be >= width and multiples of 4");
+    OTTER_REQUIRE(aligned16(x) && (!gamma || (aligned16(gamma) && aligned16(beta))) && (reinterpret_cast<uintptr_t>(y) & 7u) == 0,
+                  OTTER_ERR_ALIGNMENT, "otter_layernorm: operands must be 16-byte aligned");
+    LnArgs a{};
+    a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.y = y; a.ldy = ldy; a.rows = rows; a.width = width; a.eps = eps;
+    hipStream_t s = (hipStream_t)stream;
+    return out_f32 ? launch_ln<SRC_PLAIN, true, true>(a, s, "otter_layernorm") : launch_ln<SRC_PLAIN, false, true>(a, s, "otter_layernorm");
+}
+
+extern "C" int otter_vit_embed_lnpre(const float* patch_tok, long ld_tok, const float* class_embedding, const float* pos_embedding,
+                                     const float* gamma, const float* beta, float* x, long ldx, int n_img, int n_patches,
+                                     int width, float eps, void* stream) {
+    OTTER_REQUIRE(patch_tok && class_embedding && pos_embedding && gamma && beta && x, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_vit_embed_lnpre: null operand");
+    if (n_img == 0) return OTTER_OK;
+    OTTER_REQUIRE(n_img > 0 && n_patches > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_vit_embed_lnpre: n_img=%d n_patches=%d", n_img, n_patches);
+    if (int rc = check_width(width, "otter_vit_embed_lnpre")) return rc;
+    OTTER_REQUIRE(ld_tok >= width && ld_tok % 4 == 0 && ldx >= width && ldx % 4 == 0, OTTER_ERR_ALIGNMENT,
+                  "otter_vit_embed_lnpre: leading dimensions must be >= width and multiples of 4");
+    OTTER_REQUIRE(aligned16(patch_tok) && aligned16(class_embedding) && aligned16(pos_embedding) && aligned16(x) &&
+                  aligned16(gamma) && aligned16(beta), OTTER_ERR_ALIGNMENT, "otter_vit_embed_lnpre: operands must be 16-byte aligned");
+    LnArgs a{};
+    a.x = patch_tok; a.ldx = ld_tok; a.gamma = gamma; a.beta = beta; a.y = x; a.ldy = ldx;
+    a.rows = n_img * (n_patches + 1); a.width = width; a.eps = eps;
+    a.cls = class_embedding; a.pos = pos_embedding; a.tokens = n_patches + 1;
+    return launch_ln<SRC_VIT, true, true>(a, (hipStream_t)stream, "otter_vit_embed_lnpre");
+}
+
+extern "C" int otter_text_embed(const int* ids, int ctx, int take, const float* token_embedding, int vocab,
+                                const float* pos_embedding, float* x, long ldx, int batch, int width, void* stream) {
+    OTTER_REQUIRE(ids && token_embedding && pos_embedding && x, OTTER_ERR_INVALID_ARGUMENT, "otter_text_embed: null operand");
+    if (batch == 0) return OTTER_OK;
+    OTTER_REQUIRE(batch > 0 && take > 0 && take <= ctx && vocab > 0, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_text_embed: batch=%d take=%d ctx=%d vocab=%d", batch, take, ctx, vocab);
+    if (int rc = check_width(width, "otter_text_embed")) return rc;
+    OTTER_REQUIRE(ldx >= width && ldx % 4 == 0, OTTER_ERR_ALIGNMENT, "otter_text_embed: ldx must be >= width and a multiple of 4");
+    OTTER_REQUIRE(aligned16(token_embedding) && aligned16(pos_embedding) && aligned16(x), OTTER_ERR_ALIGNMENT,
+                  "otter_text_embed: operands must be 16-byte aligned");
+    LnArgs a{};
+    a.x = token_embedding; a.ldx = width; a.y = x; a.ldy = ldx; a.rows = batch * take; a.width = width;
+    a.pos = pos_embedding; a.ids = ids; a.ctx = ctx; a.take = take; a.vocab = vocab;
+    return launch_ln<SRC_TEXT, true, false>(a, (hipStream_t)stream, "otter_text_embed");
+}

@@ -1,0 +1,155 @@
+// Attention-pooling readout: the query side of the cross-attention blocks that compress (nk x D_in) tokens
+// into R readout vectors of width d.  The key/value projections (the only part with real FLOPs) are done by
+// the bf16 GEMM beforehand; this kernel does everything else of the pooling module in fp32, one workgroup
+// per observation, with all intermediates in LDS:
+//   per block:  qn = LN_q(q);  Q = qn Wq^T + bq;  scores = Q K^T / sqrt(hd) (+ key padding mask);
+//               softmax over keys;  ctx = P V;  q1 = qn + ctx Wo^T + bo;      (residual on the NORMALISED query)
+//               out = q1 + fc2(gelu(fc1(LN(q1))))
+//   end:        LN(out) flattened to (R*d).
+// Weights are passed transposed ([in][out]) so that consecutive threads read consecutive addresses.
+#include "common.hpp"
+#include "otter_hip.h"
+
+namespace {
+
+constexpr int MAX_BLOCKS = 4;
+
+struct ReadoutArgs {
+    otter_readout_block blk[MAX_BLOCKS];
+    int n_blocks;
+    const float* query;          // [R][d]
+    const float* final_ln_w; const float* final_ln_b;
+    const float* kv; long ldkv;  // rows (m*nk + k); block b: K at col b*2d, V at col b*2d + d
+    const unsigned char* mask;   // [M][nk] (1 = ignore key) or null
+    float* out; long ldo;        // [M][R*d]
+    int M, nk, R, d, heads, hidden;
+};
+
+__device__ __forceinline__ void ln_row(const float* in, float* out, const float* w, const float* b, int d, int lane) {
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += in[i];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int i = lane; i < d; i += 64) { const float t = in[i] - mean; q += t * t; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+    for (int i = lane; i < d; i += 64) out[i] = (in[i] - mean) * rstd * w[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = blockIdx.x;
+    const int R = p.R, d = p.d, nk = p.nk, heads = p.heads, hd = d / heads, hidden = p.hidden;
+    const int Rd = R * d;
+    float* q = sm;                    // [R][d] running query
+    float* qn = q + Rd;               // [R][d]
+    float* Q = qn + Rd;               // [R][d]  (later reused for ctx)
+    float* q1 = Q + Rd;               // [R][d]
+    float* hn = q1 + Rd;              // [R][d]
+    float* KV = hn + Rd;              // [nk][2d]
+    float* sc = KV + nk * 2 * d;      // [R][heads][nk]
+    float* h1 = sc + R * heads * nk;  // [R][hidden]
+
+    for (int i = tid; i < Rd; i += 256) q[i] = p.query[i];
+    __syncthreads();
+
+    for (int b = 0; b < p.n_blocks; ++b) {
+        const otter_readout_block& w = p.blk[b];
+        for (int r = wave; r < R; r += 4) ln_row(q + r * d, qn + r * d, w.q_ln_w, w.q_ln_b, d, lane);
+        // K | V of this observation and block
+        for (int i = tid; i < nk * 2 * d; i += 256) {
+            const int k = i / (2 * d), c = i % (2 * d);
+            KV[i] = p.kv[((long)m * nk + k) * p.ldkv + b * 2 * d + c];
+        }
+        __syncthreads();
+        for (int o = tid; o < Rd; o += 256) {
+            const int r = o / d, j = o % d;
+            float acc = w.bq[j];
+            for (int i = 0; i < d; ++i) acc += qn[r * d + i] * w.wq_t[i * d + j];
+            Q[o] = acc;
+        }
+        __syncthreads();
+        const float scale = 1.0f / sqrtf((float)hd);
+        for (int o = tid; o < R * heads * nk; o += 256) {
+            const int k = o % nk, h = (o / nk) % heads, r = o / (nk * heads);
+            float acc = 0.f;
+            for (int e = 0; e < hd; ++e) acc += Q[r * d + h * hd + e] * KV[k * 2 * d + h * hd + e];
+            acc *= scale;
+            if (p.mask && p.mask[(long)m * nk + k]) acc = -INFINITY;
+            sc[o] = acc;
+        }
+        __syncthreads();
+        for (int o = tid; o < R * heads; o += 256) {
+            float* row = sc + o * nk;
+            float mx = -INFINITY;
+            for (int k = 0; k < nk; ++k) mx = fmaxf(mx, row[k]);
+            float sum = 0.f;
+            for (int k = 0; k < nk; ++k) { const float e = expf(row[k] - mx); row[k] = e; sum += e; }
+            const float inv = 1.0f / sum;
+            for (int k = 0; k < nk; ++k) row[k] *= inv;
+        }
+        __syncthreads();
+        for (int o = tid; o < Rd; o += 256) {            // ctx -> Q (Q is dead)
+            const int r = o / d, j = o % d, h = j / hd;
+            float acc = 0.f;
+            for (int k = 0; k < nk; ++k) acc += sc[(r * heads + h) * nk + k] * KV[k * 2 * d + d + j];
+            hn[o] = acc;                                  // hn used as ctx scratch here
+        }
+        __syncthreads();
+        for (int o = tid; o < Rd; o += 256) {
+            const int r = o / d, j = o % d;
+            float acc = w.bo[j];
+            for (int i = 0; i < d; ++i) acc += hn[r * d + i] * w.wo_t[i * d + j];
+            q1[o] = qn[o] + acc;
+        }
+        __syncthreads();
+        for (int r = wave; r < R; r += 4) ln_row(q1 + r * d, hn + r * d, w.ln_w, w.ln_b, d, lane);
+        __syncthreads();
+        for (int o = tid; o < R * hidden; o += 256) {
+            const int r = o / hidden, u = o % hidden;
+            float acc = w.fc1_b[u];
+            for (int i = 0; i < d; ++i) acc += hn[r * d + i] * w.fc1_t[i * hidden + u];
+            h1[o] = gelu_erf(acc);
+        }
+        __syncthreads();
+        for (int o = tid; o < Rd; o += 256) {
+            const int r = o / d, j = o % d;
+            float acc = w.fc2_b[j];
+            for (int u = 0; u < hidden; ++u) acc += h1[r * hidden + u] * w.fc2_t[u * d + j];
+            q[o] = q1[o] + acc;
+        }
+        __syncthreads();
+    }
+    for (int r = wave; r < R; r += 4) ln_row(q + r * d, p.out + (long)m * p.ldo + r * d, p.final_ln_w, p.final_ln_b, d, lane);
+}
+
+}  // namespace
+
+extern "C" int otter_readout_pool_fwd(const otter_readout_block* blocks, int n_blocks, const float* query,
+                                      const float* final_ln_w, const float* final_ln_b, const float* kv, long ldkv,
+                                      const unsigned char* mask, float* out, long ldo, int n_obs, int nk, int readouts,
+                                      int d, int heads, int hidden, void* stream) {
+    OTTER_REQUIRE(blocks && query && final_ln_w && final_ln_b && kv && out, OTTER_ERR_INVALID_ARGUMENT, "otter_readout_pool_fwd: null operand");
+    if (n_obs == 0) return OTTER_OK;
+    OTTER_REQUIRE(n_blocks >= 1 && n_blocks <= MAX_BLOCKS, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: n_blocks=%d (1..%d)", n_blocks, MAX_BLOCKS);
+    OTTER_REQUIRE(n_obs > 0 && nk > 0 && nk <= 64 && readouts > 0 && readouts <= 16 && d > 0 && d <= 256 && heads > 0 && d % heads == 0 &&
+                  hidden > 0 && hidden <= 2048, OTTER_ERR_UNSUPPORTED_SHAPE,
+                  "otter_readout_pool_fwd: unsupported sizes nk=%d R=%d d=%d heads=%d hidden=%d", nk, readouts, d, heads, hidden);
+    OTTER_REQUIRE(ldkv >= (long)n_blocks * 2 * d && ldo >= (long)readouts * d, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_readout_pool_fwd: ldkv=%ld / ldo=%ld too small", ldkv, ldo);
+    ReadoutArgs a{};
+    for (int b = 0; b < n_blocks; ++b) {
+        a.blk[b] = blocks[b];
+        const otter_readout_block& w = blocks[b];
+        OTTER_REQUIRE(w.q_ln_w && w.q_ln_b && w.wq_t && w.bq && w.wo_t && w.bo && w.ln_w && w.ln_b && w.fc1_t && w.fc1_b && w.fc2_t && w.fc2_b,
+                      OTTER_ERR_INVALID_ARGUMENT, "otter_readout_pool_fwd: block %d has a null parameter", b);
+    }
+    a.n_blocks = n_blocks; a.query = query; a.final_ln_w = final_ln_w; a.final_ln_b = final_ln_b;
+    a.kv = kv; a.ldkv = ldkv; a.mask = mask; a.out = out; a.ldo = ldo;
+    a.M = n_obs; a.nk = nk; a.R = readouts; a.d = d; a.heads = heads; a.hidden = hidden;
+    const size_t lds = sizeof(float) * ((size_t)5 * readouts * d + (size_t)nk * 2 * d + (size_t)readouts * heads * nk + (size_t)readouts * hidden);
+    OTTER_REQUIRE(lds <= 64 * 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: needs %zu bytes of LDS (> 64 KiB)", lds);
+    hipLaunchKernelGGL(readout_kernel, dim3(n_obs), dim3(256), lds, (hipStream_t)stream, a);
+    OTTER_CHECK_LAUNCH("otter_readout_pool_fwd");
+    return OTTER_OK;
+}

@@ -1,0 +1,214 @@
+// Small memory-bound helpers around the big kernels: patch extraction (im2col with the CLIP pixel
+// normalisation fused), row L2-normalisation, fp32 small linear layers (proprioception MLP), casts,
+// row broadcast/gather, and the GPU-resident rollout window of policy inputs.
+#include "common.hpp"
+#include "otter_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------- im2col (+ /255, (x-mean)/std for uint8 input)
+// out[(img*g*g + py*g + px)][c*ps*ps + ky*ps + kx] = norm(img[c][py*ps+ky][px*ps+kx]); columns >= 3*ps*ps are zero.
+template <bool U8>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* images, __bf16* out, int res, int ps, int g, int kpad,
+                                                     float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int patch = blockIdx.x;                      // img*g*g + py*g + px
+    const int img = patch / (g * g), py = (patch / g) % g, px = patch % g;
+    const int kk = 3 * ps * ps;
+    const long img_off = (long)img * 3 * res * res;
+    for (int k = threadIdx.x; k < kpad; k += 256) {
+        float v = 0.f;
+        if (k < kk) {
+            const int c = k / (ps * ps), ky = (k / ps) % ps, kx = k % ps;
+            const long idx = img_off + ((long)c * res + (py * ps + ky)) * res + (px * ps + kx);
+            if (U8) {
+                const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), std = c == 0 ? s0 : (c == 1 ? s1 : s2);
+                v = ((float)((const unsigned char*)images)[idx] / 255.0f - mean) / std;
+            } else {
+                v = ((const float*)images)[idx];
+            }
+        }
+        out[(long)patch * kpad + k] = f32_to_bf16(v);
+    }
+}
+
+// ---------------------------------------------------------------- y = x / ||x||_2 per row (fp32 in/out)
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, long ldx, float* y, long ldy, int rows, int width) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* src = x + (long)row * ldx;
+    float sq = 0.f;
+    for (int i = lane; i < width; i += 64) sq += src[i] * src[i];
+    const float rn = 1.0f / sqrtf(wave_sum(sq));
+    for (int i = lane; i < width; i += 64) y[(long)row * ldy + i] = src[i] * rn;
+}
+
+// ---------------------------------------------------------------- y = act(x Wt + b), fp32, small shapes
+// Wt is [K][N] (transposed weight).  One workgroup handles 8 rows; x rows are staged in LDS.
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, long ldx, const float* wt, const float* bias,
+                                                         float* y, long ldy, int M, int N, int K, int act) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [8][K]
+    const int r0 = blockIdx.x * 8;
+    const int nr = min(8, M - r0);
+    for (int i = threadIdx.x; i < 8 * K; i += 256) {
+        const int r = i / K, k = i % K;
+        xs[i] = (r < nr) ? x[(long)(r0 + r) * ldx + k] : 0.f;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float acc[8];
+        const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = b;
+        for (int k = 0; k < K; ++k) {
+            const float w = wt[(long)k * N + n];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] += xs[r * K + k] * w;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < nr) {
+                float v = acc[r];
+                if (act == OTTER_EPI_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (act == OTTER_EPI_ACT_GELU) v = gelu_erf(v);
+                else if (act == OTTER_EPI_ACT_QUICKGELU) v = quick_gelu(v);
+                y[(long)(r0 + r) * ldy + n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fp32 -> bf16 with column zero-padding, optional row map
+// dst[r][c] = bf16(src[row_of(r)][c]) for c < cols, 0 for cols <= c < cols_pad.
+//   row_of(r) = r / rep                       (idx == null)
+//   row_of(r) = r * group + idx[r]            (idx != null: pick one row out of each group of `group` rows)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, long lds_, __bf16* dst, long ldd, int rows, int cols,
+                                                        int cols_pad, int rep, const int* idx, int group) {
+    const int row = blockIdx.x;
+    const long srow = idx ? (long)row * group + min(max(idx[row], 0), group - 1) : (long)(row / rep);
+    for (int c = threadIdx.x; c < cols_pad; c += 256)
+        dst[(long)row * ldd + c] = f32_to_bf16(c < cols ? src[srow * lds_ + c] : 0.f);
+}
+
+// dst[r][0:cols] = src[r / rep][0:cols]   (fp32)
+__global__ __launch_bounds__(256) void repeat_rows_kernel(const float* src, long lds_, float* dst, long ldd, int rows, int cols, int rep) {
+    const int row = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += 256) dst[(long)row * ldd + c] = src[(long)(row / rep) * lds_ + c];
+}
+
+// out[b*tq + i][:] = window[b][pos0 + i][:] + pe[pos0 + i][:]
+__global__ __launch_bounds__(256) void add_pe_kernel(const float* window, const float* pe, float* out, int S, int tq, int pos0, int dim) {
+    const int row = blockIdx.x, b = row / tq, i = row % tq;
+    const float* src = window + ((long)b * S + pos0 + i) * dim;
+    const float* p = pe + (long)(pos0 + i) * dim;
+    for (int c = threadIdx.x; c < dim; c += 256) out[(long)row * dim + c] = src[c] + p[c];
+}
+
+// Rollout window of policy inputs, one per episode (the reference's cached_transformer_input):
+//   len < S : dst = src with `fresh` written at position len      (new length len+1)
+//   len = S : dst = src shifted left by one, `fresh` at S-1       (length stays S)
+// lens_in/lens_out are per-episode; src and dst are distinct buffers (ping-pong), rows beyond the length are zero.
+__global__ __launch_bounds__(256) void window_append_kernel(const float* src, const float* fresh, float* dst, const int* lens_in,
+                                                            int* lens_out, int S, int dim) {
+    const int b = blockIdx.x / S, j = blockIdx.x % S;
+    const int len = min(max(lens_in[b], 0), S);
+    const bool full = (len == S);
+    const float* from = nullptr;
+    if (full) from = (j < S - 1) ? src + ((long)b * S + j + 1) * dim : fresh + (long)b * dim;
+    else if (j < len) from = src + ((long)b * S + j) * dim;
+    else if (j == len) from = fresh + (long)b * dim;
+    for (int c = threadIdx.x; c < dim; c += 256) dst[((long)b * S + j) * dim + c] = from ? from[c] : 0.f;
+    if (j == 0 && threadIdx.x == 0) lens_out[b] = full ? S : len + 1;
+}
+
+}  // namespace
+
+extern "C" int otter_im2col_patches(const void* images, int is_u8, void* out, int n_img, int res, int patch, int kpad,
+                                    const float* mean3, const float* std3, void* stream) {
+    OTTER_REQUIRE(images && out, OTTER_ERR_INVALID_ARGUMENT, "otter_im2col_patches: null operand");
+    if (n_img == 0) return OTTER_OK;
+    OTTER_REQUIRE(n_img > 0 && res > 0 && patch > 0 && res % patch == 0, OTTER_ERR_UNSUPPORTED_SHAPE,
+                  "otter_im2col_patches: res=%d must be a positive multiple of patch=%d", res, patch);
+    OTTER_REQUIRE(kpad >= 3 * patch * patch && kpad % 64 == 0, OTTER_ERR_UNSUPPORTED_SHAPE,
+                  "otter_im2col_patches: kpad=%d must be a multiple of 64 and >= %d", kpad, 3 * patch * patch);
+    const int g = res / patch;
+    OTTER_REQUIRE((long)n_img * g * g < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_im2col_patches: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (is_u8) {
+        OTTER_REQUIRE(mean3 && std3, OTTER_ERR_INVALID_ARGUMENT, "otter_im2col_patches: uint8 input needs mean/std (host pointers)");
+        hipLaunchKernelGGL(im2col_kernel<true>, dim3(n_img * g * g), dim3(256), 0, s, images, (__bf16*)out, res, patch, g, kpad,
+                           mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    } else {
+        hipLaunchKernelGGL(im2col_kernel<false>, dim3(n_img * g * g), dim3(256), 0, s, images, (__bf16*)out, res, patch, g, kpad,
+                           0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
+    }
+    OTTER_CHECK_LAUNCH("otter_im2col_patches");
+    return OTTER_OK;
+}
+
+extern "C" int otter_l2norm_rows(const float* x, long ldx, float* y, long ldy, int rows, int width, void* stream) {
+    OTTER_REQUIRE(x && y, OTTER_ERR_INVALID_ARGUMENT, "otter_l2norm_rows: null operand");
+    if (rows == 0) return OTTER_OK;
+    OTTER_REQUIRE(rows > 0 && width > 0 && ldx >= width && ldy >= width, OTTER_ERR_INVALID_ARGUMENT, "otter_l2norm_rows: bad sizes");
+    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, width);
+    OTTER_CHECK_LAUNCH("otter_l2norm_rows");
+    return OTTER_OK;
+}
+
+extern "C" int otter_linear_f32(const float* x, long ldx, const float* wt, const float* bias, float* y, long ldy,
+                                int M, int N, int K, int act, void* stream) {
+    OTTER_REQUIRE(x && wt && y, OTTER_ERR_INVALID_ARGUMENT, "otter_linear_f32: null operand");
+    if (M == 0) return OTTER_OK;
+    OTTER_REQUIRE(M > 0 && N > 0 && K > 0 && K <= 2048, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_linear_f32: M=%d N=%d K=%d (K <= 2048)", M, N, K);
+    OTTER_REQUIRE(ldx >= K && ldy >= N, OTTER_ERR_INVALID_ARGUMENT, "otter_linear_f32: leading dimensions too small");
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((M + 7) / 8), dim3(256), sizeof(float) * 8 * K, (hipStream_t)stream,
+                       x, ldx, wt, bias, y, ldy, M, N, K, act);
+    OTTER_CHECK_LAUNCH("otter_linear_f32");
+    return OTTER_OK;
+}
+
+extern "C" int otter_cast_bf16(const float* src, long ld_src, void* dst, long ld_dst, int rows, int cols, int cols_pad,
+                               int rep, const int* pick, int group, void* stream) {
+    OTTER_REQUIRE(src && dst, OTTER_ERR_INVALID_ARGUMENT, "otter_cast_bf16: null operand");
+    if (rows == 0) return OTTER_OK;
+    OTTER_REQUIRE(rows > 0 && cols > 0 && cols_pad >= cols && ld_src >= cols && ld_dst >= cols_pad && rep >= 1, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_cast_bf16: bad sizes");
+    OTTER_REQUIRE(!pick || group >= 1, OTTER_ERR_INVALID_ARGUMENT, "otter_cast_bf16: pick needs group >= 1");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, src, ld_src, (__bf16*)dst, ld_dst, rows, cols,
+                       cols_pad, rep, pick, group);
+    OTTER_CHECK_LAUNCH("otter_cast_bf16");
+    return OTTER_OK;
+}
+
+extern "C" int otter_repeat_rows(const float* src, long ld_src, float* dst, long ld_dst, int rows, int cols, int rep, void* stream) {
+    OTTER_REQUIRE(src && dst, OTTER_ERR_INVALID_ARGUMENT, "otter_repeat_rows: null operand");
+    if (rows == 0) return OTTER_OK;
+    OTTER_REQUIRE(rows > 0 && cols > 0 && rep >= 1 && ld_src >= cols && ld_dst >= cols, OTTER_ERR_INVALID_ARGUMENT, "otter_repeat_rows: bad sizes");
+    hipLaunchKernelGGL(repeat_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, rows, cols, rep);
+    OTTER_CHECK_LAUNCH("otter_repeat_rows");
+    return OTTER_OK;
+}
+
+extern "C" int otter_add_pe(const float* window, const float* pe, float* out, int batch, int window_len, int n_query, int pos0,
+                            int dim, void* stream) {
+    OTTER_REQUIRE(window && pe && out, OTTER_ERR_INVALID_ARGUMENT, "otter_add_pe: null operand");
+    if (batch == 0 || n_query == 0) return OTTER_OK;
+    OTTER_REQUIRE(batch > 0 && n_query > 0 && pos0 >= 0 && pos0 + n_query <= window_len && dim > 0, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_add_pe: positions %d..%d outside the window of %d", pos0, pos0 + n_query - 1, window_len);
+    hipLaunchKernelGGL(add_pe_kernel, dim3(batch * n_query), dim3(256), 0, (hipStream_t)stream, window, pe, out, window_len, n_query, pos0, dim);
+    OTTER_CHECK_LAUNCH("otter_add_pe");
+    return OTTER_OK;
+}
+
+extern "C" int otter_window_append(const float* src, const float* fresh, float* dst, const int* lens_in, int* lens_out,
+                                   int batch, int window_len, int dim, void* stream) {
+    OTTER_REQUIRE(src && fresh && dst && lens_in && lens_out, OTTER_ERR_INVALID_ARGUMENT, "otter_window_append: null operand");
+    OTTER_REQUIRE(src != dst && lens_in != lens_out, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_window_append: src/dst and lens_in/lens_out must be different buffers");
+    if (batch == 0) return OTTER_OK;
+    OTTER_REQUIRE(batch > 0 && window_len > 0 && dim > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_window_append: bad sizes");
+    hipLaunchKernelGGL(window_append_kernel, dim3(batch * window_len), dim3(256), 0, (hipStream_t)stream, src, fresh, dst, lens_in,
+                       lens_out, window_len, dim);
+    OTTER_CHECK_LAUNCH("otter_window_append");
+    return OTTER_OK;
+}

@@ -1,0 +1,342 @@
+"""Tensor-level wrappers over the C ABI.
+
+torch is used for device memory and the current HIP stream only; every function here checks shapes,
+dtypes, device and contiguity on the host (a kernel that reads out of bounds can take the GPU down) and then
+passes raw pointers to ``libotter_hip.so``.  No function here computes anything in torch.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, OUT_F32, RESIDUAL, OtterHipError, ReadoutBlock  # noqa: F401
+
+Tensor = torch.Tensor
+GEMM_N_ALIGN = 128
+GEMM_K_ALIGN = 64
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: Tensor, dtype, name: str, dims: Optional[int] = None) -> Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if t.device.type != "cuda":
+        raise OtterHipError(f"{name}: tensor is on {t.device}; the HIP path needs device memory (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if dims is not None and t.dim() != dims:
+        raise ValueError(f"{name}: {t.dim()} dims, expected {dims}")
+    if t.stride(-1) != 1 and t.numel() > 0 and t.shape[-1] != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+    return t
+
+
+def _rows_view(t: Tensor, name: str) -> tuple:
+    """(rows, cols, ld) of a 2-D row-major view with arbitrary row stride."""
+    if t.dim() != 2:
+        raise ValueError(f"{name}: expected 2-D, got {tuple(t.shape)}")
+    return t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------------------- weight packing
+
+def pack_weight(w: Tensor, device=None) -> Tensor:
+    """torch Linear weight (N, K) fp32 -> bf16 (N rounded up to 128, K rounded up to 64), zero padded."""
+    n, k = w.shape
+    out = torch.zeros(round_up(n, GEMM_N_ALIGN), round_up(k, GEMM_K_ALIGN), dtype=torch.bfloat16, device=device or w.device)
+    out[:n, :k] = w.to(device=out.device, dtype=torch.bfloat16)
+    return out
+
+
+# ----------------------------------------------------------------------------------------- kernels
+
+def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
+         out_f32: bool = False, residual: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """out[M, n] = epilogue(a[M, K] @ w[n, K]^T + bias); ``w_packed`` from :func:`pack_weight`."""
+    _chk(a, torch.bfloat16, "gemm.a")
+    _chk(w_packed, torch.bfloat16, "gemm.w", 2)
+    m, k, lda = _rows_view(a, "gemm.a")
+    if not w_packed.is_contiguous() or w_packed.shape[1] != k:
+        raise ValueError(f"gemm: weight {tuple(w_packed.shape)} does not match K={k} (activations must carry the padded K)")
+    if w_packed.shape[0] < round_up(n, GEMM_N_ALIGN):
+        raise ValueError(f"gemm: packed weight has {w_packed.shape[0]} rows, needs {round_up(n, GEMM_N_ALIGN)}")
+    if bias is not None:
+        _chk(bias, torch.float32, "gemm.bias", 1)
+        if bias.numel() < n:
+            raise ValueError("gemm: bias shorter than N")
+    epi = act | (OUT_F32 if (out_f32 or residual is not None) else 0) | (RESIDUAL if residual is not None else 0)
+    odt = torch.float32 if (epi & OUT_F32) else torch.bfloat16
+    if out is None:
+        out = torch.empty(m, n, dtype=odt, device=a.device)
+    _chk(out, odt, "gemm.out")
+    mo, no, ldc = _rows_view(out, "gemm.out")
+    if mo != m or no != n:
+        raise ValueError(f"gemm: out is {tuple(out.shape)}, expected ({m}, {n})")
+    ldr = 0
+    if residual is not None:
+        _chk(residual, torch.float32, "gemm.residual")
+        mr, nr, ldr = _rows_view(residual, "gemm.residual")
+        if mr != m or nr != n:
+            raise ValueError("gemm: residual shape mismatch")
+    if m == 0:
+        return out
+    _lib.call("otter_gemm_bf16", _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
+              _ptr(out), ldc, m, n, k, epi, _stream())
+    return out
+
+
+def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], *, eps: float = 1e-5, out_f32: bool = False,
+              out: Optional[Tensor] = None) -> Tensor:
+    _chk(x, torch.float32, "layernorm.x")
+    rows, width, ldx = _rows_view(x, "layernorm.x")
+    for t, nm in ((gamma, "gamma"), (beta, "beta")):
+        if t is not None:
+            _chk(t, torch.float32, "layernorm." + nm, 1)
+            if t.numel() != width:
+                raise ValueError(f"layernorm.{nm}: {t.numel()} elements, expected {width}")
+    odt = torch.float32 if out_f32 else torch.bfloat16
+    if out is None:
+        out = torch.empty(rows, width, dtype=odt, device=x.device)
+    _chk(out, odt, "layernorm.out")
+    ro, wo, ldy = _rows_view(out, "layernorm.out")
+    if ro != rows or wo != width:
+        raise ValueError("layernorm: out shape mismatch")
+    _lib.call("otter_layernorm", _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(out), ldy, rows, width, eps, int(out_f32), _stream())
+    return out
+
+
+def vit_embed_lnpre(patch_tok: Tensor, cls: Tensor, pos: Tensor, gamma: Tensor, beta: Tensor, n_img: int, n_patches: int,
+                    eps: float = 1e-5) -> Tensor:
+    _chk(patch_tok, torch.float32, "vit_embed.patch_tok", 2)
+    rows, width, ld = _rows_view(patch_tok, "vit_embed.patch_tok")
+    if rows != n_img * n_patches:
+        raise ValueError(f"vit_embed: {rows} patch rows, expected {n_img * n_patches}")
+    _chk(cls, torch.float32, "vit_embed.cls", 1)
+    _chk(pos, torch.float32, "vit_embed.pos", 2)
+    if cls.numel() != width or tuple(pos.shape) != (n_patches + 1, width) or not pos.is_contiguous():
+        raise ValueError("vit_embed: class/positional embedding shape mismatch")
+    for t in (gamma, beta):
+        _chk(t, torch.float32, "vit_embed.ln", 1)
+        if t.numel() != width:
+            raise ValueError("vit_embed: ln_pre width mismatch")
+    x = torch.empty(n_img * (n_patches + 1), width, dtype=torch.float32, device=patch_tok.device)
+    _lib.call("otter_vit_embed_lnpre", _ptr(patch_tok), ld, _ptr(cls), _ptr(pos), _ptr(gamma), _ptr(beta), _ptr(x), width,
+              n_img, n_patches, width, eps, _stream())
+    return x
+
+
+def text_embed(ids: Tensor, take: int, token_embedding: Tensor, pos: Tensor) -> Tensor:
+    _chk(ids, torch.int32, "text_embed.ids", 2)
+    if not ids.is_contiguous():
+        raise ValueError("text_embed.ids must be contiguous")
+    b, ctx = ids.shape
+    _chk(token_embedding, torch.float32, "text_embed.table", 2)
+    _chk(pos, torch.float32, "text_embed.pos", 2)
+    vocab, width = token_embedding.shape
+    if not token_embedding.is_contiguous() or not pos.is_contiguous() or pos.shape[1] != width or pos.shape[0] < take:
+        raise ValueError("text_embed: table/positional embedding shape mismatch")
+    if not (0 < take <= ctx):
+        raise ValueError(f"text_embed: take={take} outside 1..{ctx}")
+    x = torch.empty(b * take, width, dtype=torch.float32, device=ids.device)
+    _lib.call("otter_text_embed", _ptr(ids), ctx, take, _ptr(token_embedding), vocab, _ptr(pos), _ptr(x), width, b, width, _stream())
+    return x
+
+
+def im2col_patches(images: Tensor, patch: int, kpad: int, mean: Sequence[float], std: Sequence[float]) -> Tensor:
+    """images (N, 3, R, R) uint8 (normalisation fused) or float32 (already normalised) -> bf16 (N*g*g, kpad)."""
+    if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != images.shape[3]:
+        raise ValueError(f"im2col: expected (N, 3, R, R), got {tuple(images.shape)}")
+    if images.dtype not in (torch.uint8, torch.float32):
+        raise TypeError(f"im2col: dtype {images.dtype}; uint8 or float32")
+    _chk(images, images.dtype, "im2col.images")
+    if not images.is_contiguous():
+        raise ValueError("im2col: images must be contiguous")
+    n, _, res, _ = images.shape
+    g = res // patch
+    out = torch.empty(n * g * g, kpad, dtype=torch.bfloat16, device=images.device)
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    _lib.call("otter_im2col_patches", _ptr(images), int(images.dtype == torch.uint8), _ptr(out), n, res, patch, kpad, m3, s3, _stream())
+    return out
+
+
+def attn_d64(qkv: Tensor, n_seq: int, seq_len: int, heads: int, causal: bool) -> Tensor:
+    _chk(qkv, torch.bfloat16, "attn.qkv", 2)
+    rows, width, ld = _rows_view(qkv, "attn.qkv")
+    if rows != n_seq * seq_len or width != 3 * heads * 64:
+        raise ValueError(f"attn: qkv {tuple(qkv.shape)} does not match n_seq={n_seq} L={seq_len} heads={heads}")
+    out = torch.empty(rows, heads * 64, dtype=torch.bfloat16, device=qkv.device)
+    _lib.call("otter_attn_fwd_d64", _ptr(qkv), ld, _ptr(out), heads * 64, n_seq, seq_len, heads, int(causal), _stream())
+    return out
+
+
+def attn_policy(qkv_cache: Tensor, n_query: int, pos0: int, heads: int) -> Tensor:
+    """qkv_cache (B, S, 3*dim) fp32 -> bf16 (B*n_query, dim)."""
+    _chk(qkv_cache, torch.float32, "attn_policy.qkv", 3)
+    if not qkv_cache.is_contiguous():
+        raise ValueError("attn_policy: cache must be contiguous")
+    b, s, w3 = qkv_cache.shape
+    dim = w3 // 3
+    if dim * 3 != w3 or dim % heads != 0:
+        raise ValueError("attn_policy: bad cache width")
+    if pos0 < 0 or pos0 + n_query > s:
+        raise ValueError(f"attn_policy: positions {pos0}..{pos0 + n_query - 1} outside window {s}")
+    out = torch.empty(b * n_query, dim, dtype=torch.bfloat16, device=qkv_cache.device)
+    _lib.call("otter_attn_policy", _ptr(qkv_cache), w3, _ptr(out), dim, b, s, n_query, pos0, heads, dim // heads, _stream())
+    return out
+
+
+def pos_emb_transpose(pos: Tensor) -> Tensor:
+    _chk(pos, torch.float32, "pos_emb", 2)
+    if not pos.is_contiguous():
+        raise ValueError("pos_emb must be contiguous")
+    p, d = pos.shape
+    out = torch.empty(d, p, dtype=torch.bfloat16, device=pos.device)
+    _lib.call("otter_pos_emb_transpose", _ptr(pos), _ptr(out), p, d, _stream())
+    return out
+
+
+def text_aware_pool(patches: Tensor, text: Tensor, pos_t: Tensor, temperature: Tensor, n_obs: int, cams: int, t_rep: int) -> Tensor:
+    """patches bf16 (n_obs*cams, P, D); text fp32 (n_obs/t_rep, K, D); pos_t bf16 (cams, D, P); -> fp32 (cams, n_obs, K, D)."""
+    _chk(patches, torch.bfloat16, "tave.patches", 3)
+    _chk(text, torch.float32, "tave.text", 3)
+    _chk(pos_t, torch.bfloat16, "tave.posT", 3)
+    _chk(temperature, torch.float32, "tave.temperature", 1)
+    units, p, d = patches.shape
+    nt, k, d2 = text.shape
+    if units != n_obs * cams or d2 != d or n_obs % t_rep != 0 or nt != n_obs // t_rep:
+        raise ValueError(f"tave: patches {tuple(patches.shape)}, text {tuple(text.shape)}, n_obs={n_obs}, cams={cams}, t_rep={t_rep}")
+    if tuple(pos_t.shape) != (cams, d, p) or temperature.numel() != cams:
+        raise ValueError("tave: pos_t / temperature shape mismatch")
+    for t in (patches, text, pos_t, temperature):
+        if not t.is_contiguous():
+            raise ValueError("tave: operands must be contiguous")
+    out = torch.empty(cams, n_obs, k, d, dtype=torch.float32, device=patches.device)
+    _lib.call("otter_text_aware_pool_fwd", _ptr(patches), _ptr(text), _ptr(pos_t), _ptr(temperature), _ptr(out), n_obs, cams,
+              p, d, k, t_rep, _stream())
+    return out
+
+
+def readout_pool(blocks, query: Tensor, final_w: Tensor, final_b: Tensor, kv: Tensor, mask: Optional[Tensor], out: Tensor,
+                 n_obs: int, nk: int, readouts: int, d: int, heads: int, hidden: int) -> Tensor:
+    """``blocks``: ctypes array of :class:`ReadoutBlock`; kv fp32 (n_obs*nk, >= n_blocks*2d); out fp32 view (n_obs, readouts*d)."""
+    _chk(kv, torch.float32, "readout.kv", 2)
+    rows, _, ldkv = _rows_view(kv, "readout.kv")
+    if rows != n_obs * nk:
+        raise ValueError("readout: kv rows mismatch")
+    _chk(out, torch.float32, "readout.out", 2)
+    ro, wo, ldo = _rows_view(out, "readout.out")
+    if ro != n_obs or wo != readouts * d:
+        raise ValueError("readout: out shape mismatch")
+    if mask is not None:
+        _chk(mask, torch.uint8, "readout.mask", 2)
+        if tuple(mask.shape) != (n_obs, nk) or not mask.is_contiguous():
+            raise ValueError("readout: mask shape mismatch")
+    for t, nme, cnt in ((query, "query", readouts * d), (final_w, "final_w", d), (final_b, "final_b", d)):
+        _chk(t, torch.float32, "readout." + nme)
+        if t.numel() != cnt or not t.is_contiguous():
+            raise ValueError(f"readout.{nme}: bad size")
+    _lib.call("otter_readout_pool_fwd", blocks, len(blocks), _ptr(query), _ptr(final_w), _ptr(final_b), _ptr(kv), ldkv, _ptr(mask),
+              _ptr(out), ldo, n_obs, nk, readouts, d, heads, hidden, _stream())
+    return out
+
+
+def l2norm_rows(x: Tensor) -> Tensor:
+    _chk(x, torch.float32, "l2norm.x", 2)
+    rows, width, ldx = _rows_view(x, "l2norm.x")
+    y = torch.empty(rows, width, dtype=torch.float32, device=x.device)
+    _lib.call("otter_l2norm_rows", _ptr(x), ldx, _ptr(y), width, rows, width, _stream())
+    return y
+
+
+def linear_f32(x: Tensor, wt: Tensor, bias: Optional[Tensor], act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
+    """fp32 small linear: x (M, K), wt (K, N) transposed weight."""
+    _chk(x, torch.float32, "linear_f32.x", 2)
+    _chk(wt, torch.float32, "linear_f32.wt", 2)
+    m, k, ldx = _rows_view(x, "linear_f32.x")
+    if wt.shape[0] != k or not wt.is_contiguous():
+        raise ValueError("linear_f32: weight shape mismatch")
+    n = wt.shape[1]
+    if bias is not None:
+        _chk(bias, torch.float32, "linear_f32.bias", 1)
+        if bias.numel() != n:
+            raise ValueError("linear_f32: bias size mismatch")
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    _chk(out, torch.float32, "linear_f32.out", 2)
+    mo, no, ldy = _rows_view(out, "linear_f32.out")
+    if mo != m or no != n:
+        raise ValueError("linear_f32: out shape mismatch")
+    _lib.call("otter_linear_f32", _ptr(x), ldx, _ptr(wt), _ptr(bias), _ptr(out), ldy, m, n, k, act, _stream())
+    return out
+
+
+def cast_bf16(src: Tensor, cols_pad: Optional[int] = None, rep: int = 1, pick: Optional[Tensor] = None, group: int = 1,
+              rows: Optional[int] = None) -> Tensor:
+    """fp32 (R, C) -> bf16 (rows, cols_pad); see ``otter_cast_bf16`` for the row maps."""
+    _chk(src, torch.float32, "cast.src", 2)
+    r, c, lds = _rows_view(src, "cast.src")
+    cols_pad = cols_pad or c
+    if pick is not None:
+        _chk(pick, torch.int32, "cast.pick", 1)
+        n_rows = pick.numel()
+        if n_rows * group != r:
+            raise ValueError("cast: pick/group do not match the source rows")
+    else:
+        n_rows = rows if rows is not None else r * rep
+        if (n_rows - 1) // rep >= r:
+            raise ValueError("cast: rep maps past the source rows")
+    dst = torch.empty(n_rows, cols_pad, dtype=torch.bfloat16, device=src.device)
+    _lib.call("otter_cast_bf16", _ptr(src), lds, _ptr(dst), cols_pad, n_rows, c, cols_pad, rep, _ptr(pick), group, _stream())
+    return dst
+
+
+def repeat_rows(src: Tensor, dst: Tensor, rep: int) -> Tensor:
+    _chk(src, torch.float32, "repeat.src", 2)
+    _chk(dst, torch.float32, "repeat.dst", 2)
+    r, c, lds = _rows_view(src, "repeat.src")
+    rd, cd, ldd = _rows_view(dst, "repeat.dst")
+    if cd != c or rd != r * rep:
+        raise ValueError("repeat_rows: shape mismatch")
+    _lib.call("otter_repeat_rows", _ptr(src), lds, _ptr(dst), ldd, rd, c, rep, _stream())
+    return dst
+
+
+def add_pe(window: Tensor, pe: Tensor, n_query: int, pos0: int) -> Tensor:
+    _chk(window, torch.float32, "add_pe.window", 3)
+    _chk(pe, torch.float32, "add_pe.pe", 2)
+    b, s, dim = window.shape
+    if not window.is_contiguous() or not pe.is_contiguous() or pe.shape[1] != dim or pe.shape[0] < pos0 + n_query:
+        raise ValueError("add_pe: shape mismatch")
+    out = torch.empty(b * n_query, dim, dtype=torch.float32, device=window.device)
+    _lib.call("otter_add_pe", _ptr(window), _ptr(pe), _ptr(out), b, s, n_query, pos0, dim, _stream())
+    return out
+
+
+def window_append(src: Tensor, fresh: Tensor, dst: Tensor, lens_in: Tensor, lens_out: Tensor) -> None:
+    _chk(src, torch.float32, "window.src", 3)
+    _chk(dst, torch.float32, "window.dst", 3)
+    _chk(fresh, torch.float32, "window.fresh", 2)
+    _chk(lens_in, torch.int32, "window.lens_in", 1)
+    _chk(lens_out, torch.int32, "window.lens_out", 1)
+    b, s, dim = src.shape
+    if dst.shape != src.shape or tuple(fresh.shape) != (b, dim) or lens_in.numel() != b or lens_out.numel() != b:
+        raise ValueError("window_append: shape mismatch")
+    for t in (src, dst, fresh):
+        if not t.is_contiguous():
+            raise ValueError("window_append: operands must be contiguous")
+    _lib.call("otter_window_append", _ptr(src), _ptr(fresh), _ptr(dst), _ptr(lens_in), _ptr(lens_out), b, s, dim, _stream())

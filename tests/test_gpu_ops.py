@@ -1,0 +1,284 @@
+"""Per-kernel parity on the GPU: each C-ABI entry point against a plain fp32 torch / oracle computation of the
+same op on the same (bf16-rounded) inputs.  Tolerances are written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import otter_ref as R  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from otter_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _randn(seed, *shape):
+    return torch.randn(*shape, generator=_g(seed))
+
+
+def _act(name, x):
+    if name == "quickgelu":
+        return x * torch.sigmoid(1.702 * x)
+    if name == "gelu":
+        return torch.nn.functional.gelu(x)
+    if name == "relu":
+        return torch.relu(x)
+    return x
+
+
+ACTS = {"none": 0, "quickgelu": 1, "gelu": 2, "relu": 3}
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 256, 128), (1000, 3072, 1024), (129, 120, 1536), (5, 768, 704), (2056, 1024, 4096),
+                                   (1, 128, 64)])
+@pytest.mark.parametrize("act", ["none", "quickgelu", "gelu", "relu"])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_gemm(dev, m, n, k, act, out_f32):
+    from otter_amd import ops
+    a = _randn(1, m, k).to(dev).bfloat16()
+    w = (_randn(2, n, k) / math.sqrt(k)).to(dev)
+    bias = _randn(3, n).to(dev)
+    wp = ops.pack_weight(w)
+    kp = wp.shape[1]
+    if kp != k:
+        a_p = torch.zeros(m, kp, dtype=torch.bfloat16, device=dev)
+        a_p[:, :k] = a
+    else:
+        a_p = a
+    out = ops.gemm(a_p, wp, n, bias, act=ACTS[act], out_f32=out_f32)
+    ref = _act(act, a.float() @ w.bfloat16().float().t() + bias)
+    assert out.shape == (m, n)
+    # fp32 accumulation of exact bf16 products: error is summation order only; bf16 output adds 2^-9 relative
+    tol = dict(rtol=2e-3, atol=2e-3) if out_f32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out.float(), ref, **tol)
+
+
+def test_gemm_residual_strided_inplace(dev):
+    from otter_amd import ops
+    m, n, k = 777, 1024, 1024
+    big_a = torch.zeros(m, k + 64, dtype=torch.bfloat16, device=dev)
+    a = big_a[:, :k]
+    a.copy_(_randn(4, m, k))
+    w = (_randn(5, n, k) / math.sqrt(k)).to(dev)
+    bias = _randn(6, n).to(dev)
+    res = _randn(7, m, n).to(dev)
+    ref = a.float() @ w.bfloat16().float().t() + bias + res
+    out = ops.gemm(a, ops.pack_weight(w), n, bias, residual=res, out=res)      # in place on the residual stream
+    assert out.data_ptr() == res.data_ptr()
+    torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-3)
+    # rows of an output with a larger leading dimension stay untouched outside [0, n)
+    wide = torch.full((m, n + 8), 7.0, device=dev)
+    ops.gemm(a, ops.pack_weight(w), n, bias, out_f32=True, out=wide[:, :n])
+    assert torch.all(wide[:, n:] == 7.0)
+
+
+def test_gemm_rejects_bad_arguments(dev):
+    from otter_amd import ops
+    a = torch.zeros(4, 100, dtype=torch.bfloat16, device=dev)     # K not a multiple of 64
+    w = torch.zeros(128, 100, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(ops.OtterHipError):
+        ops.gemm(a, w, 128)
+    with pytest.raises(ops.OtterHipError):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), w, 128)   # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("rows,width", [(37, 1024), (1, 768), (1000, 768), (9, 128), (5, 4096), (3, 64)])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_layernorm(dev, rows, width, out_f32):
+    from otter_amd import ops
+    x = (_randn(8, rows, width) * 3 + 1).to(dev)
+    g = (_randn(9, width) * 0.2 + 1).to(dev)
+    b = _randn(10, width).to(dev)
+    y = ops.layernorm(x, g, b, out_f32=out_f32)
+    ref = torch.nn.functional.layer_norm(x, (width,), g, b, 1e-5)
+    tol = dict(rtol=1e-5, atol=1e-5) if out_f32 else dict(rtol=8e-3, atol=8e-3)   # bf16 rounding of the output
+    torch.testing.assert_close(y.float(), ref, **tol)
+    y2 = ops.layernorm(x, None, None, out_f32=True)
+    torch.testing.assert_close(y2, torch.nn.functional.layer_norm(x, (width,)), rtol=1e-5, atol=1e-5)
+
+
+def test_vit_embed_and_text_embed(dev):
+    from otter_amd import ops
+    n_img, p, w = 3, 16, 128
+    tok = _randn(11, n_img * p, w).to(dev)
+    cls = _randn(12, w).to(dev)
+    pos = _randn(13, p + 1, w).to(dev)
+    g = (_randn(14, w) * 0.1 + 1).to(dev)
+    b = _randn(15, w).to(dev)
+    x = ops.vit_embed_lnpre(tok, cls, pos, g, b, n_img, p)
+    full = torch.cat([cls.expand(n_img, 1, w), tok.view(n_img, p, w)], 1) + pos
+    ref = torch.nn.functional.layer_norm(full, (w,), g, b, 1e-5).view(-1, w)
+    torch.testing.assert_close(x, ref, rtol=1e-5, atol=1e-5)
+
+    ids = torch.randint(0, 500, (4, 77), generator=_g(16)).int().to(dev)
+    table = _randn(17, 500, 64).to(dev)
+    tpos = _randn(18, 77, 64).to(dev)
+    for take in (15, 77, 1):
+        e = ops.text_embed(ids, take, table, tpos)
+        ref = (table[ids[:, :take].long()] + tpos[:take]).view(-1, 64)
+        torch.testing.assert_close(e, ref, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", ["u8", "f32"])
+def test_im2col(dev, dtype):
+    from otter_amd import ops
+    n, res, ps = 3, 56, 14
+    if dtype == "u8":
+        img = torch.randint(0, 256, (n, 3, res, res), generator=_g(19), dtype=torch.uint8).to(dev)
+        ref_img = R.clip_transform(img.cpu()).to(dev)
+    else:
+        img = _randn(20, n, 3, res, res).to(dev)
+        ref_img = img
+    kpad = ops.round_up(3 * ps * ps, 64)
+    out = ops.im2col_patches(img, ps, kpad, R.CLIP_MEAN, R.CLIP_STD)
+    ref = torch.nn.functional.unfold(ref_img, ps, stride=ps).transpose(1, 2).reshape(-1, 3 * ps * ps)
+    assert torch.all(out[:, 3 * ps * ps:] == 0)
+    # bit-exact after rounding the fp32 normalised pixel to bf16
+    assert torch.equal(out[:, :3 * ps * ps], ref.bfloat16())
+
+
+def _sdpa_ref(qkv, n_seq, L, heads, hd, causal):
+    q, k, v = qkv.float().view(n_seq, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=qkv.device).triu(1)
+    return (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(n_seq * L, heads * hd)
+
+
+@pytest.mark.parametrize("n_seq,L,heads,causal", [(3, 257, 16, False), (2, 15, 12, True), (2, 77, 12, True), (5, 17, 2, False),
+                                                  (1, 1, 1, True), (2, 65, 2, False), (1, 288, 1, False)])
+def test_attn_d64(dev, n_seq, L, heads, causal):
+    from otter_amd import ops
+    qkv = _randn(21, n_seq * L, 3 * heads * 64).to(dev).bfloat16()
+    out = ops.attn_d64(qkv, n_seq, L, heads, causal)
+    ref = _sdpa_ref(qkv, n_seq, L, heads, 64, causal)
+    # P is rounded to bf16 before P.V and the output is bf16: ~2^-8 relative on O(1) values
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=1.5e-2)
+
+
+def test_attn_d64_peaked_softmax(dev):
+    """Large logits (one dominant key per query) must not overflow or lose the row maximum."""
+    from otter_amd import ops
+    n_seq, L, heads = 1, 257, 2
+    qkv = _randn(22, n_seq * L, 3 * heads * 64).to(dev)
+    qkv[:, : heads * 64] *= 12.0
+    qkv = qkv.bfloat16()
+    out = ops.attn_d64(qkv, n_seq, L, heads, False)
+    ref = _sdpa_ref(qkv, n_seq, L, heads, 64, False)
+    assert torch.isfinite(out.float()).all()
+    torch.testing.assert_close(out.float(), ref, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("b,s,nq,pos0,heads,hd", [(3, 12, 12, 0, 8, 96), (3, 12, 1, 0, 8, 96), (3, 12, 1, 7, 8, 96), (2, 32, 32, 0, 8, 96),
+                                                  (2, 4, 2, 1, 2, 64)])
+def test_attn_policy(dev, b, s, nq, pos0, heads, hd):
+    from otter_amd import ops
+    dim = heads * hd
+    cache = _randn(23, b, s, 3 * dim).to(dev)
+    out = ops.attn_policy(cache, nq, pos0, heads)
+    q, k, v = cache.view(b, s, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + torch.full((s, s), float("-inf"), device=dev).triu(1)
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(b, s, dim)[:, pos0:pos0 + nq].reshape(b * nq, dim)
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)     # bf16 output rounding
+
+
+@pytest.mark.parametrize("n_obs,cams,P,D,K,t_rep", [(2, 2, 256, 768, 15, 1), (6, 2, 256, 768, 15, 3), (3, 1, 64, 128, 15, 1),
+                                                    (2, 2, 16, 128, 1, 2), (1, 2, 256, 768, 16, 1)])
+@pytest.mark.parametrize("temperature", [0.07, 0.005, 150.0])
+def test_text_aware_pool(dev, n_obs, cams, P, D, K, t_rep, temperature):
+    from otter_amd import ops
+    patches = (_randn(24, n_obs * cams, P, D) * 1.7).to(dev).bfloat16()
+    text = (_randn(25, n_obs // t_rep, K, D) * 0.3).to(dev)
+    pos = torch.stack([R.sincos_position_embedding(P, D) * (1 + 0.1 * c) for c in range(cams)]).to(dev)
+    temp = torch.full((cams,), temperature, device=dev)
+    pos_t = torch.stack([ops.pos_emb_transpose(pos[c]) for c in range(cams)])
+    out = ops.text_aware_pool(patches, text, pos_t, temp, n_obs, cams, t_rep)
+    pf = patches.float().view(n_obs, cams, P, D)
+    pf = pf / pf.norm(dim=-1, keepdim=True)
+    tf = (text / text.norm(dim=-1, keepdim=True)).repeat_interleave(t_rep, 0)
+    for c in range(cams):
+        ref = R.text_aware_visual_extraction(pf[:, c].cpu(), tf.cpu(), torch.tensor(temperature), pos[c].cpu()).to(dev)
+        # bf16 rounding of text tokens, softmax weights and pos_emb: ~2^-8 relative to |pos_emb| <= 1; the logit
+        # error from the bf16 text tokens is amplified by 1/temperature (200x at 0.005)
+        tol = 4e-2 if temperature < 0.01 else 1e-2
+        torch.testing.assert_close(out[c], ref, rtol=2e-2, atol=tol)
+
+
+@pytest.mark.parametrize("case_name", ["vision_nomask", "text_mask", "small"])
+def test_readout_pool(dev, case_name):
+    import golden_inputs as GI
+    from otter_amd import ops
+    from otter_amd.params import pooling_specs, random_state_dict
+    from otter_amd.pooling import PoolingWeights
+    case = next(c for c in GI.POOL_CASES if c["name"] == case_name)
+    sd = random_state_dict(pooling_specs("", case["D_in"], case["D_out"], case["layers"], case["readouts"]), seed=case["seed"])
+    x, mask = GI.pool_inputs(case)
+    ref = R.attention_pooling(x, sd, "", case["heads"], mask)
+    pw = PoolingWeights({k: v.to(dev) for k, v in sd.items()}, "", case["heads"])
+    out = torch.zeros(case["B"], case["D_out"] + 8, device=dev)
+    pw.forward(x.to(dev).reshape(-1, case["D_in"]), None if mask is None else mask.to(dev), out[:, 4:4 + case["D_out"]], case["B"], case["K"])
+    # k/v projections run on bf16 MFMA (inputs rounded to bf16), the rest is fp32
+    torch.testing.assert_close(out[:, 4:4 + case["D_out"]].cpu(), ref, rtol=2e-2, atol=2e-2)
+    assert torch.all(out[:, :4] == 0) and torch.all(out[:, 4 + case["D_out"]:] == 0)
+
+
+def test_small_ops(dev):
+    from otter_amd import ops
+    x = _randn(26, 33, 768).to(dev)
+    torch.testing.assert_close(ops.l2norm_rows(x), x / x.norm(dim=-1, keepdim=True), rtol=1e-5, atol=1e-6)
+    # fp32 linear chain (proprio MLP shapes)
+    h = _randn(27, 19, 10).to(dev)
+    w = _randn(28, 256, 10).to(dev)
+    b = _randn(29, 256).to(dev)
+    y = ops.linear_f32(h, w.t().contiguous(), b, ops.ACT_RELU)
+    torch.testing.assert_close(y, torch.relu(h @ w.t() + b), rtol=1e-5, atol=1e-5)
+    # cast with padding and repetition
+    c = ops.cast_bf16(x[:5, :700].contiguous(), cols_pad=704, rep=3)
+    assert c.shape == (15, 704) and torch.all(c[:, 700:] == 0)
+    assert torch.equal(c[:, :700], x[:5, :700].bfloat16().repeat_interleave(3, 0))
+    pick = torch.tensor([0, 3, 1], dtype=torch.int32, device=dev)
+    src = _randn(30, 12, 64).to(dev)
+    sel = ops.cast_bf16(src, pick=pick, group=4)
+    assert torch.equal(sel, src.view(3, 4, 64)[torch.arange(3), pick.long().cpu()].bfloat16())
+    dst = torch.zeros(10, 40, device=dev)
+    ops.repeat_rows(src[:5, :32], dst[:, 4:36], 2)
+    assert torch.equal(dst[:, 4:36], src[:5, :32].repeat_interleave(2, 0)) and torch.all(dst[:, :4] == 0)
+    # positional embedding add over a window slice
+    win = _randn(31, 3, 12, 64).to(dev)
+    pe = _randn(32, 12, 64).to(dev)
+    torch.testing.assert_close(ops.add_pe(win, pe, 5, 4), (win[:, 4:9] + pe[4:9]).reshape(-1, 64), rtol=0, atol=0)
+
+
+def test_window_append_matches_reference_cache(dev):
+    """otter.py:158-175: concatenate on the time axis, keep the last seq_length entries."""
+    from otter_amd import ops
+    B, S, dim = 3, 4, 64
+    bufs = [torch.zeros(B, S, dim, device=dev), torch.zeros(B, S, dim, device=dev)]
+    lens = [torch.tensor([0, 2, 4], dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)]
+    hist = [[], [_randn(40, dim), _randn(41, dim)], [_randn(42 + i, dim) for i in range(4)]]
+    for b in range(B):
+        for j, v in enumerate(hist[b]):
+            bufs[0][b, j] = v.to(dev)
+    cur = 0
+    for step in range(6):
+        fresh = _randn(100 + step, B, dim)
+        ops.window_append(bufs[cur], fresh.to(dev), bufs[cur ^ 1], lens[cur], lens[cur ^ 1])
+        cur ^= 1
+        for b in range(B):
+            hist[b] = (hist[b] + [fresh[b]])[-S:]
+            n = int(lens[cur][b])
+            assert n == len(hist[b])
+            assert torch.equal(bufs[cur][b, :n].cpu(), torch.stack(hist[b]))
+            assert torch.all(bufs[cur][b, n:] == 0)

@@ -11,7 +11,9 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+
+DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
 # epilogue word (mirrors include/otter_hip.h)
 ACT_NONE, ACT_QUICKGELU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
@@ -31,19 +33,19 @@ class ReadoutBlock(Structure):
 _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
 
 _SIGNATURES = {
-    "otter_gemm_bf16": [_P, _L, _P, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "otter_gemm": [_I, _P, _L, _P, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "otter_layernorm": [_P, _L, _P, _P, _P, _L, _I, _I, _F, _I, _P],
     "otter_vit_embed_lnpre": [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P],
     "otter_text_embed": [_P, _I, _I, _P, _I, _P, _P, _L, _I, _I, _P],
-    "otter_im2col_patches": [_P, _I, _P, _I, _I, _I, _I, POINTER(c_float), POINTER(c_float), _P],
-    "otter_attn_fwd_d64": [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "otter_im2col_patches": [_I, _P, _I, _P, _I, _I, _I, _I, POINTER(c_float), POINTER(c_float), _P],
+    "otter_attn_fwd_d64": [_I, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "otter_attn_policy": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P],
-    "otter_text_aware_pool_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "otter_pos_emb_transpose": [_P, _P, _I, _I, _P],
+    "otter_text_aware_pool_fwd": [_I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "otter_pos_emb_transpose": [_I, _P, _P, _I, _I, _P],
     "otter_readout_pool_fwd": [POINTER(ReadoutBlock), _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
-    "otter_l2norm_rows": [_P, _L, _P, _L, _I, _I, _P],
+    "otter_l2norm_rows": [_I, _P, _L, _P, _L, _I, _I, _P],
     "otter_linear_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
-    "otter_cast_bf16": [_P, _L, _P, _L, _I, _I, _I, _I, _P, _I, _P],
+    "otter_convert_rows": [_I, _P, _L, _P, _L, _I, _I, _I, _I, _P, _I, _I, _P],
     "otter_repeat_rows": [_P, _L, _P, _L, _I, _I, _I, _P],
     "otter_add_pe": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "otter_window_append": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -17,8 +17,8 @@
 namespace {
 
 struct AttnArgs {
-    const __bf16* qkv; long ld;      // rows (seq*L + t), q|k|v blocks of heads*64 each
-    __bf16* out; long ldo;
+    const void* qkv; long ld;        // rows (seq*L + t), q|k|v blocks of heads*64 each (bf16 or fp16)
+    void* out; long ldo;
     int L, heads, causal;
     float scale;
 };
@@ -26,9 +26,13 @@ struct AttnArgs {
 __device__ __forceinline__ int k_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 __device__ __forceinline__ int v_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }
 
-template <int NKT>   // NKT = number of 16-key tiles the registers hold (even)
+template <typename T, int NKT>   // NKT = number of 16-key tiles the registers hold (even)
 __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Half16<T>::v8 v8;
+    typedef typename Half16<T>::v4 v4;
+    const T* qkv = (const T*)p.qkv;
+    T* outp = (T*)p.out;
     constexpr int LK = NKT * 16;
     char* sK = smem;
     char* sV = smem + LK * 128;
@@ -41,14 +45,14 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
     // ---- stage K and V of this head (rows >= L are zero) ----
     for (int idx = tid; idx < LK * 8; idx += 256) {
         const int r = idx >> 3, c = idx & 7;
-        bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+        s16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
         if (r < L) {
-            const __bf16* base = p.qkv + (row0 + r) * p.ld + h * 64 + c * 8;
-            kv = *(const bf16x8*)(base + hd);
-            vv = *(const bf16x8*)(base + 2 * hd);
+            const T* base = qkv + (row0 + r) * p.ld + h * 64 + c * 8;
+            kv = *(const s16x8*)(base + hd);
+            vv = *(const s16x8*)(base + 2 * hd);
         }
-        *(bf16x8*)(sK + r * 128 + (k_swz(r, c) << 4)) = kv;
-        *(bf16x8*)(sV + r * 128 + (v_swz(r, c) << 4)) = vv;
+        *(s16x8*)(sK + r * 128 + (k_swz(r, c) << 4)) = kv;
+        *(s16x8*)(sV + r * 128 + (v_swz(r, c) << 4)) = vv;
     }
     __syncthreads();
 
@@ -64,10 +68,10 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
     for (int qt = wave; qt < nqt; qt += 4) {
         const int q = qt * 16 + li;                // this lane's query
         const int qc = min(q, L - 1);
-        bf16x8 qf[2];
+        v8 qf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            qf[ks] = *(const bf16x8*)(p.qkv + (row0 + qc) * p.ld + h * 64 + ks * 32 + g * 8);
+            qf[ks] = *(const v8*)(qkv + (row0 + qc) * p.ld + h * 64 + ks * 32 + g * 8);
 
         // Every one of the NKT key tiles is computed, also those past L (their K rows are zero in LDS and the
         // mask below removes them): a wave-uniform skip here would put a branch between an MFMA and the first
@@ -78,8 +82,8 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(sK + kt * 2048 + k_row_off + (((ks * 4 + g) ^ k_sw) << 4));
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                const v8 kf = *(const v8*)(sK + kt * 2048 + k_row_off + (((ks * 4 + g) ^ k_sw) << 4));
+                s[kt] = Half16<T>::mfma32(kf, qf[ks], s[kt]);
             }
         }
         // ---- mask + softmax over keys (per lane: one query) ----
@@ -116,11 +120,11 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
 #pragma unroll
         for (int s2 = 0; s2 < NKT / 2; ++s2) {
             {
-                bf16x8 pf;
+                v8 pf;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pf[r] = f32_to_bf16(s[2 * s2][r]);
-                    pf[4 + r] = f32_to_bf16(s[2 * s2 + 1][r]);
+                    pf[r] = Half16<T>::from(s[2 * s2][r]);
+                    pf[4 + r] = Half16<T>::from(s[2 * s2 + 1][r]);
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -130,28 +134,28 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
                         (__attribute__((address_space(3))) s16x4*)(sV + rlo * 128 + (v_swz(rlo, cl) << 4) + sub));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(sV + rhi * 128 + (v_swz(rhi, cl) << 4) + sub));
-                    union { struct { s16x4 a, b; } h; bf16x8 v; } u;
+                    union { struct { s16x4 a, b; } h; v8 v; } u;
                     u.h.a = lo; u.h.b = hi;
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf, o[dt], 0, 0, 0);
+                    o[dt] = Half16<T>::mfma32(u.v, pf, o[dt]);
                 }
             }
         }
         if (q < L) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                bf16x4 ob;
+                v4 ob;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(o[dt][r] * inv);
-                *(bf16x4*)(p.out + (row0 + q) * p.ldo + h * 64 + dt * 16 + g * 4) = ob;
+                for (int r = 0; r < 4; ++r) ob[r] = Half16<T>::from(o[dt][r] * inv);
+                *(v4*)(outp + (row0 + q) * p.ldo + h * 64 + dt * 16 + g * 4) = ob;
             }
         }
     }
 }
 
-template <int NKT>
+template <typename T, int NKT>
 int launch_d64(const AttnArgs& a, int n_seq, hipStream_t s) {
     constexpr int lds = NKT * 16 * 128 * 2;
-    auto kern = attn_d64<NKT>;
+    auto kern = attn_d64<T, NKT>;
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -168,7 +172,7 @@ int launch_d64(const AttnArgs& a, int n_seq, hipStream_t s) {
 // attends keys 0 .. pos0+i of the same episode's rows (the rows double as the GPU-resident K/V history).
 struct PolicyAttnArgs {
     const float* qkv; long ld;      // row (b*S + t)
-    __bf16* out; long ldo;          // row (b*Tq + i)
+    float* out; long ldo;           // row (b*Tq + i)
     int S, Tq, pos0, heads, hd;
     float scale;
 };
@@ -200,14 +204,22 @@ __global__ __launch_bounds__(256) void attn_policy(PolicyAttnArgs p, int total) 
             const float pj = __shfl(e, j, 64);
             acc += pj * p.qkv[((long)b * p.S + j) * p.ld + 2 * dim + h * p.hd + d];
         }
-        p.out[((long)b * p.Tq + i) * p.ldo + h * p.hd + d] = f32_to_bf16(acc * inv);
+        p.out[((long)b * p.Tq + i) * p.ldo + h * p.hd + d] = acc * inv;
     }
 }
 
 }  // namespace
 
-extern "C" int otter_attn_fwd_d64(const void* qkv, long ld, void* out, long ldo, int n_seq, int L, int heads,
+template <typename T>
+static int dispatch_d64(const AttnArgs& a, int n_seq, int L, hipStream_t s) {
+    if (L <= 32) return launch_d64<T, 2>(a, n_seq, s);
+    if (L <= 96) return launch_d64<T, 6>(a, n_seq, s);
+    return launch_d64<T, 18>(a, n_seq, s);
+}
+
+extern "C" int otter_attn_fwd_d64(int dtype, const void* qkv, long ld, void* out, long ldo, int n_seq, int L, int heads,
                                   int causal, void* stream) {
+    OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_fwd_d64: dtype %d (bf16 or fp16)", dtype);
     OTTER_REQUIRE(qkv && out, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_fwd_d64: null operand");
     if (n_seq == 0) return OTTER_OK;
     OTTER_REQUIRE(n_seq > 0 && L > 0 && heads > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_fwd_d64: n_seq=%d L=%d heads=%d", n_seq, L, heads);
@@ -216,14 +228,12 @@ extern "C" int otter_attn_fwd_d64(const void* qkv, long ld, void* out, long ldo,
                   "otter_attn_fwd_d64: ld=%ld / ldo=%ld too small or misaligned for %d heads", ld, ldo, heads);
     OTTER_REQUIRE(aligned16(qkv) && aligned16(out), OTTER_ERR_ALIGNMENT, "otter_attn_fwd_d64: operands must be 16-byte aligned");
     OTTER_REQUIRE((long)n_seq * heads < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_attn_fwd_d64: grid too large");
-    AttnArgs a{(const __bf16*)qkv, ld, (__bf16*)out, ldo, L, heads, causal ? 1 : 0, 0.125f};
+    AttnArgs a{qkv, ld, out, ldo, L, heads, causal ? 1 : 0, 0.125f};
     hipStream_t s = (hipStream_t)stream;
-    if (L <= 32) return launch_d64<2>(a, n_seq, s);
-    if (L <= 96) return launch_d64<6>(a, n_seq, s);
-    return launch_d64<18>(a, n_seq, s);
+    return dtype == DT_BF16 ? dispatch_d64<__bf16>(a, n_seq, L, s) : dispatch_d64<_Float16>(a, n_seq, L, s);
 }
 
-extern "C" int otter_attn_policy(const float* qkv, long ld, void* out, long ldo, int batch, int window, int n_query,
+extern "C" int otter_attn_policy(const float* qkv, long ld, float* out, long ldo, int batch, int window, int n_query,
                                  int pos0, int heads, int head_dim, void* stream) {
     OTTER_REQUIRE(qkv && out, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_policy: null operand");
     if (batch == 0 || n_query == 0) return OTTER_OK;
@@ -234,7 +244,7 @@ extern "C" int otter_attn_policy(const float* qkv, long ld, void* out, long ldo,
     OTTER_REQUIRE(head_dim % 4 == 0 && ld >= 3L * heads * head_dim && ld % 4 == 0 && ldo >= (long)heads * head_dim,
                   OTTER_ERR_ALIGNMENT, "otter_attn_policy: head_dim must be a multiple of 4 and ld/ldo large enough");
     OTTER_REQUIRE(aligned16(qkv), OTTER_ERR_ALIGNMENT, "otter_attn_policy: qkv must be 16-byte aligned");
-    PolicyAttnArgs a{qkv, ld, (__bf16*)out, ldo, window, n_query, pos0, heads, head_dim, 1.0f / sqrtf((float)head_dim)};
+    PolicyAttnArgs a{qkv, ld, out, ldo, window, n_query, pos0, heads, head_dim, 1.0f / sqrtf((float)head_dim)};
     const long total = (long)batch * heads * n_query;
     OTTER_REQUIRE(total < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_attn_policy: grid too large");
     hipLaunchKernelGGL(attn_policy, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, (int)total);

@@ -8,7 +8,10 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -46,6 +49,37 @@ void otter_set_error(const char* fmt, ...);   // defined in capi.hip (thread-loc
     } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- element types ------------------------------------------------------------------------------
+// Data type codes of the C ABI (OTTER_DT_* in otter_hip.h).
+enum { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
+
+// 16-bit MFMA operand types.  bf16 keeps fp32's range; fp16 carries 3 more mantissa bits at the same MFMA rate
+// (CLIP's published weights are fp16).  Conversions to fp16 saturate instead of overflowing to infinity.
+template <typename T> struct Half16;
+template <> struct Half16<__bf16> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ __bf16 from(float v) { return (__bf16)v; }
+    static __device__ __forceinline__ f32x4 mfma32(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+};
+template <> struct Half16<_Float16> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ _Float16 from(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
+    static __device__ __forceinline__ f32x4 mfma32(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) {
+        union { s16x4 s; f16x4 h; } ua, ub;
+        ua.s = a; ub.s = b;
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(ua.h, ub.h, c, 0, 0, 0);
+    }
+};
+template <typename T> __device__ __forceinline__ short bits16(T v) {
+    union { T t; short s; } u;
+    u.t = v;
+    return u.s;
+}
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }

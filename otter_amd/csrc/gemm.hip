@@ -1,12 +1,18 @@
-// bf16 MFMA GEMM with fused epilogues:  C[M,N] = epi(A[M,K] * W[N,K]^T + bias [+ residual]).
+// MFMA GEMM with fused epilogues:  C[M,N] = epi(A[M,K] * W[N,K]^T + bias [+ residual]).
+//
+// Operand types: bf16 or fp16 (v_mfma_f32_16x16x32_*; the CLIP towers) and fp32 (v_mfma_f32_16x16x4_f32, an exact
+// fp32 fma chain; the small policy / pooling / head layers whose outputs must match an fp32 reference closely).
+// Accumulation is fp32 in every case.
 //
 // Both operands are K-contiguous (activations row-major, weights in torch's [out,in] layout), so the
 // same LDS image and fragment read serve both.  Structure (one workgroup = 4 waves = 128x128 output tile):
 //   * global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), two LDS stages so
-//     the load of K-step t+1 overlaps the MFMAs of step t;
+//     the load of K-step t+1 overlaps the MFMAs of step t; a K-step is 128 bytes of K per row (64 halves / 32 floats);
 //   * the LDS image is lane-linear as LDS-DMA requires; bank conflicts are removed by an XOR swizzle of the
 //     16-byte chunk index applied to the per-lane SOURCE address and again on the ds_read_b128 address;
-//   * v_mfma_f32_16x16x32_bf16, 4x4 accumulator tiles per wave (64x64), fp32 accumulation;
+//   * 4x4 accumulator tiles of 16x16 per wave (64x64);
+//   * for fp32 operands a lane's 16-byte chunk holds 4 consecutive k; element e of every lane feeds MFMA step e,
+//     which permutes k identically for both operands;
 //   * the weight rows are the MFMA "A" operand and the activation rows the "B" operand, so an accumulator
 //     register quad holds 4 consecutive output columns of one output row -> 8/16-byte epilogue stores;
 //   * workgroup ids are remapped per XCD and walked in groups of 8 row-tiles so concurrently resident
@@ -16,13 +22,14 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 128;                           // bytes of K per tile row and K-step
+constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;       // 32 KiB
 constexpr int GROUP_M = 8;
 
 struct GemmArgs {
-    const __bf16* A; long lda;
-    const __bf16* W;            // [n_pad][K]
+    const char* A; long lda;    // lda, ldw in elements
+    const char* W;              // [n_pad][K]
     const float* bias;          // [N] or null
     const float* residual; long ldr;
     void* C; long ldc;
@@ -38,9 +45,25 @@ template <int ACT> __device__ __forceinline__ float apply_act(float v) {
     return v;
 }
 
-template <int ACT, bool OUT_F32, bool RES>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_128x128(GemmArgs p) {
+template <typename T> struct Frag { typedef typename Half16<T>::v8 type; };
+template <> struct Frag<float> { typedef f32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ f32x4 mma(const typename Frag<T>::type& w, const typename Frag<T>::type& a, f32x4 c) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], a[e], c, 0, 0, 0);
+        return c;
+    } else {
+        return Half16<T>::mfma32(w, a, c);
+    }
+}
+
+template <typename T, int ACT, bool OUT_F32, bool RES>
+__global__ __launch_bounds__(256, 2) void gemm_128x128(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Frag<T>::type frag_t;
+    constexpr int ES = sizeof(T);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
 
@@ -56,20 +79,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128(GemmArgs p) {
     // ---- staging source addresses (4 LDS-DMA instructions per operand per wave and K-step) ----
     // instruction i of wave w fills LDS rows (4w+i)*8 .. +7; lane l -> row +(l>>3), physical chunk l&7,
     // which holds logical chunk (l&7) ^ ((row>>1)&7).
-    const __bf16* a_src[4];
-    const __bf16* w_src[4];
+    const char* a_src[4];
+    const char* w_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const int am = min(m0 + r, p.M - 1);                 // clamp: rows past M are never stored
-        a_src[i] = p.A + (long)am * p.lda + c * 8;
-        w_src[i] = p.W + (long)(n0 + r) * p.K + c * 8;       // weights are padded to a tile multiple
+        a_src[i] = p.A + ((long)am * p.lda) * ES + c * 16;
+        w_src[i] = p.W + ((long)(n0 + r) * p.K) * ES + c * 16;   // weights are padded to a tile multiple
     }
 
     // ---- fragment read offsets ----
     const int swz = (lane >> 1) & 7;                         // ((row>>1)&7) with row = 16*t + (lane&15)
-    const int row_off = (lane & 15) * (BK * 2);
+    const int row_off = (lane & 15) * ROW_BYTES;
     int frag_off[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) frag_off[ks] = row_off + ((((ks * 4) + (lane >> 4)) ^ swz) << 4);
@@ -80,37 +103,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto stage = [&](int buf, int k0) {
+    auto stage = [&](int buf, long kbyte) {
         char* sA = smem + buf * STAGE_BYTES;
-        char* sW = sA + BM * BK * 2;
+        char* sW = sA + BM * ROW_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + k0), LDS_PTR(sA + (wave * 4 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_src[i] + k0), LDS_PTR(sW + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_src[i] + kbyte), LDS_PTR(sA + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_src[i] + kbyte), LDS_PTR(sW + (wave * 4 + i) * 1024), 16, 0, 0);
         }
     };
 
-    const int nk = p.K / BK;
+    const int nk = (p.K * ES) / ROW_BYTES;
     stage(0, 0);
     __syncthreads();                                          // drains the LDS-DMA (vmcnt(0)) + barrier
 
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nk) stage(cur ^ 1, (t + 1) * BK);
-        const char* sA = smem + cur * STAGE_BYTES + wm * 64 * (BK * 2);
-        const char* sW = smem + cur * STAGE_BYTES + BM * BK * 2 + wn * 64 * (BK * 2);
+        if (t + 1 < nk) stage(cur ^ 1, (long)(t + 1) * ROW_BYTES);
+        const char* sA = smem + cur * STAGE_BYTES + wm * 64 * ROW_BYTES;
+        const char* sW = smem + cur * STAGE_BYTES + BM * ROW_BYTES + wn * 64 * ROW_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[4], af[4];
+            frag_t wf[4], af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(sW + i * 16 * (BK * 2) + frag_off[ks]);
+            for (int i = 0; i < 4; ++i) wf[i] = *(const frag_t*)(sW + i * 16 * ROW_BYTES + frag_off[ks]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(sA + j * 16 * (BK * 2) + frag_off[ks]);
+            for (int j = 0; j < 4; ++j) af[j] = *(const frag_t*)(sA + j * 16 * ROW_BYTES + frag_off[ks]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma<T>(wf[i], af[j], acc[i][j]);
         }
         __syncthreads();
     }
@@ -131,65 +153,84 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e]);
             if (RES) v += *(const f32x4*)(p.residual + (long)m * p.ldr + n);
-            if (OUT_F32) {
+            if constexpr (OUT_F32 || sizeof(T) == 4) {
                 *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
             } else {
-                bf16x4 o;
+                typename Half16<T>::v4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[e]);
-                *(bf16x4*)((__bf16*)p.C + (long)m * p.ldc + n) = o;
+                for (int e = 0; e < 4; ++e) o[e] = Half16<T>::from(v[e]);
+                *(typename Half16<T>::v4*)((T*)p.C + (long)m * p.ldc + n) = o;
             }
         }
     }
 }
 
-template <int ACT, bool OUT_F32, bool RES>
+template <typename T, int ACT, bool OUT_F32, bool RES>
 int launch(const GemmArgs& a, hipStream_t s) {
-    auto kern = gemm_bf16_128x128<ACT, OUT_F32, RES>;
+    auto kern = gemm_128x128<T, ACT, OUT_F32, RES>;
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         configured = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), 2 * STAGE_BYTES, s, a);
-    OTTER_CHECK_LAUNCH("otter_gemm_bf16");
+    OTTER_CHECK_LAUNCH("otter_gemm");
     return OTTER_OK;
+}
+
+template <typename T, int ACT>
+int pick_out(const GemmArgs& a, bool out_f32, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+        return launch<T, ACT, true, false>(a, s);
+    } else {
+        return out_f32 ? launch<T, ACT, true, false>(a, s) : launch<T, ACT, false, false>(a, s);
+    }
+}
+
+template <typename T>
+int dispatch(const GemmArgs& a, int act, bool out_f32, bool res, hipStream_t s) {
+    if (res) return launch<T, ACT_NONE, true, true>(a, s);
+    switch (act) {
+        case OTTER_EPI_ACT_NONE: return pick_out<T, ACT_NONE>(a, out_f32, s);
+        case OTTER_EPI_ACT_QUICKGELU: return pick_out<T, ACT_QUICKGELU>(a, out_f32, s);
+        case OTTER_EPI_ACT_GELU: return pick_out<T, ACT_GELU>(a, out_f32, s);
+        case OTTER_EPI_ACT_RELU: return pick_out<T, ACT_RELU>(a, out_f32, s);
+    }
+    otter_set_error("otter_gemm: unknown activation %d", act);
+    return OTTER_ERR_INVALID_ARGUMENT;
 }
 
 }  // namespace
 
-extern "C" int otter_gemm_bf16(const void* A, long lda, const void* W, int n_pad, const float* bias,
-                               const float* residual, long ldr, void* C, long ldc, int M, int N, int K,
-                               int epilogue, void* stream) {
-    OTTER_REQUIRE(A && W && C, OTTER_ERR_INVALID_ARGUMENT, "otter_gemm_bf16: null operand");
-    OTTER_REQUIRE(M > 0 && N > 0 && K > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
-    OTTER_REQUIRE(K % BK == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_bf16: K=%d must be a multiple of %d (pad the operands)", K, BK);
-    OTTER_REQUIRE(N % 4 == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_bf16: N=%d must be a multiple of 4", N);
+extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias,
+                          const float* residual, long ldr, void* C, long ldc, int M, int N, int K,
+                          int epilogue, void* stream) {
+    OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16 || dtype == DT_F32, OTTER_ERR_INVALID_ARGUMENT, "otter_gemm: unknown dtype %d", dtype);
+    const int es = dtype == DT_F32 ? 4 : 2;
+    const int kq = ROW_BYTES / es;
+    OTTER_REQUIRE(A && W && C, OTTER_ERR_INVALID_ARGUMENT, "otter_gemm: null operand");
+    OTTER_REQUIRE(M > 0 && N > 0 && K > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_gemm: empty problem M=%d N=%d K=%d", M, N, K);
+    OTTER_REQUIRE(K % kq == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm: K=%d must be a multiple of %d (pad the operands)", K, kq);
+    OTTER_REQUIRE(N % 4 == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm: N=%d must be a multiple of 4", N);
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     OTTER_REQUIRE(n_pad >= tiles_n * BN, OTTER_ERR_INVALID_ARGUMENT,
-                  "otter_gemm_bf16: weight has %d rows, needs >= %d (pad N to a multiple of %d)", n_pad, tiles_n * BN, BN);
-    OTTER_REQUIRE(lda >= K && lda % 8 == 0, OTTER_ERR_ALIGNMENT, "otter_gemm_bf16: lda=%ld must be >= K and a multiple of 8", lda);
-    const bool out_f32 = (epilogue & OTTER_EPI_OUT_F32) != 0, res = (epilogue & OTTER_EPI_RESIDUAL) != 0;
+                  "otter_gemm: weight has %d rows, needs >= %d (pad N to a multiple of %d)", n_pad, tiles_n * BN, BN);
+    OTTER_REQUIRE(lda >= K && (lda * es) % 16 == 0, OTTER_ERR_ALIGNMENT, "otter_gemm: lda=%ld must be >= K and give 16-byte aligned rows", lda);
+    const bool out_f32 = (epilogue & OTTER_EPI_OUT_F32) != 0 || dtype == DT_F32, res = (epilogue & OTTER_EPI_RESIDUAL) != 0;
     const int act = epilogue & OTTER_EPI_ACT_MASK;
-    OTTER_REQUIRE(ldc >= N && ldc % 4 == 0, OTTER_ERR_ALIGNMENT, "otter_gemm_bf16: ldc=%ld must be >= N and a multiple of 4", ldc);
+    OTTER_REQUIRE(ldc >= N && ldc % 4 == 0, OTTER_ERR_ALIGNMENT, "otter_gemm: ldc=%ld must be >= N and a multiple of 4", ldc);
     OTTER_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C) && (!bias || aligned16(bias)), OTTER_ERR_ALIGNMENT,
-                  "otter_gemm_bf16: operands must be 16-byte aligned");
-    OTTER_REQUIRE((long)tiles_m * tiles_n < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_bf16: too many tiles");
+                  "otter_gemm: operands must be 16-byte aligned");
+    OTTER_REQUIRE((long)tiles_m * tiles_n < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm: too many tiles");
     if (res) {
         OTTER_REQUIRE(residual && aligned16(residual) && ldr >= N && ldr % 4 == 0, OTTER_ERR_INVALID_ARGUMENT,
-                      "otter_gemm_bf16: residual epilogue needs an aligned fp32 residual with ldr >= N");
+                      "otter_gemm: residual epilogue needs an aligned fp32 residual with ldr >= N");
         OTTER_REQUIRE(out_f32 && act == OTTER_EPI_ACT_NONE, OTTER_ERR_UNSUPPORTED_SHAPE,
-                      "otter_gemm_bf16: residual epilogue is fp32-out, no activation");
+                      "otter_gemm: residual epilogue is fp32-out, no activation");
     }
-    GemmArgs a{(const __bf16*)A, lda, (const __bf16*)W, bias, residual, ldr, C, ldc, M, N, K, tiles_m, tiles_n};
+    GemmArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, tiles_m, tiles_n};
     hipStream_t s = (hipStream_t)stream;
-    if (res) return launch<ACT_NONE, true, true>(a, s);
-    switch (act) {
-        case OTTER_EPI_ACT_NONE: return out_f32 ? launch<ACT_NONE, true, false>(a, s) : launch<ACT_NONE, false, false>(a, s);
-        case OTTER_EPI_ACT_QUICKGELU: return out_f32 ? launch<ACT_QUICKGELU, true, false>(a, s) : launch<ACT_QUICKGELU, false, false>(a, s);
-        case OTTER_EPI_ACT_GELU: return out_f32 ? launch<ACT_GELU, true, false>(a, s) : launch<ACT_GELU, false, false>(a, s);
-        case OTTER_EPI_ACT_RELU: return out_f32 ? launch<ACT_RELU, true, false>(a, s) : launch<ACT_RELU, false, false>(a, s);
-    }
-    otter_set_error("otter_gemm_bf16: unknown epilogue 0x%x", epilogue);
-    return OTTER_ERR_INVALID_ARGUMENT;
+    if (dtype == DT_BF16) return dispatch<__bf16>(a, act, out_f32, res, s);
+    if (dtype == DT_F16) return dispatch<_Float16>(a, act, out_f32, res, s);
+    return dispatch<float>(a, act, true, res, s);
 }

@@ -24,7 +24,7 @@ struct LnArgs {
     const int* ids; int ctx, take, vocab;                 // row = b*take + t reads ids[b*ctx + t]
 };
 
-template <int NV, int SRC, bool OUT_F32, bool NORMALISE>
+template <int NV, int SRC, int OUT_DT, bool NORMALISE>
 __global__ __launch_bounds__(256) void ln_rows(LnArgs p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -81,22 +81,27 @@ __global__ __launch_bounds__(256) void ln_rows(LnArgs p) {
             o = (v[i] - mean) * rstd;
             if (p.gamma) o = o * *(const f32x4*)(p.gamma + idx * 4) + *(const f32x4*)(p.beta + idx * 4);
         }
-        if (OUT_F32) {
+        if constexpr (OUT_DT == DT_F32) {
             *(f32x4*)((float*)p.y + (long)row * p.ldy + idx * 4) = o;
-        } else {
+        } else if constexpr (OUT_DT == DT_BF16) {
             bf16x4 ob;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ob[e] = f32_to_bf16(o[e]);
+            for (int e = 0; e < 4; ++e) ob[e] = Half16<__bf16>::from(o[e]);
             *(bf16x4*)((__bf16*)p.y + (long)row * p.ldy + idx * 4) = ob;
+        } else {
+            f16x4 ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = Half16<_Float16>::from(o[e]);
+            *(f16x4*)((_Float16*)p.y + (long)row * p.ldy + idx * 4) = ob;
         }
     }
 }
 
-template <int SRC, bool OUT_F32, bool NORMALISE>
+template <int SRC, int OUT_DT, bool NORMALISE>
 int launch_ln(const LnArgs& a, hipStream_t s, const char* name) {
     const int grid = (a.rows + 3) / 4;
-    if (a.width <= 1024) hipLaunchKernelGGL((ln_rows<4, SRC, OUT_F32, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((ln_rows<16, SRC, OUT_F32, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
+    if (a.width <= 1024) hipLaunchKernelGGL((ln_rows<4, SRC, OUT_DT, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_rows<16, SRC, OUT_DT, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
     OTTER_CHECK_LAUNCH(name);
     return OTTER_OK;
 }
@@ -110,7 +115,7 @@ int check_width(int width, const char* name) {
 }  // namespace
 
 extern "C" int otter_layernorm(const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
-                               int rows, int width, float eps, int out_f32, void* stream) {
+                               int rows, int width, float eps, int out_dtype, void* stream) {
     OTTER_REQUIRE(x && y && ((gamma == nullptr) == (beta == nullptr)), OTTER_ERR_INVALID_ARGUMENT,
                   "otter_layernorm: null operand (gamma and beta must both be given or both be NULL)");
     if (rows == 0) return OTTER_OK;
@@ -123,7 +128,11 @@ extern "C" int otter_layernorm(const float* x, long ldx, const float* gamma, con
     LnArgs a{};
     a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.y = y; a.ldy = ldy; a.rows = rows; a.width = width; a.eps = eps;
     hipStream_t s = (hipStream_t)stream;
-    return out_f32 ? launch_ln<SRC_PLAIN, true, true>(a, s, "otter_layernorm") : launch_ln<SRC_PLAIN, false, true>(a, s, "otter_layernorm");
+    if (out_dtype == DT_F32) return launch_ln<SRC_PLAIN, DT_F32, true>(a, s, "otter_layernorm");
+    if (out_dtype == DT_BF16) return launch_ln<SRC_PLAIN, DT_BF16, true>(a, s, "otter_layernorm");
+    if (out_dtype == DT_F16) return launch_ln<SRC_PLAIN, DT_F16, true>(a, s, "otter_layernorm");
+    otter_set_error("otter_layernorm: unknown out_dtype %d", out_dtype);
+    return OTTER_ERR_INVALID_ARGUMENT;
 }
 
 extern "C" int otter_vit_embed_lnpre(const float* patch_tok, long ld_tok, const float* class_embedding, const float* pos_embedding,
@@ -142,7 +151,7 @@ extern "C" int otter_vit_embed_lnpre(const float* patch_tok, long ld_tok, const 
     a.x = patch_tok; a.ldx = ld_tok; a.gamma = gamma; a.beta = beta; a.y = x; a.ldy = ldx;
     a.rows = n_img * (n_patches + 1); a.width = width; a.eps = eps;
     a.cls = class_embedding; a.pos = pos_embedding; a.tokens = n_patches + 1;
-    return launch_ln<SRC_VIT, true, true>(a, (hipStream_t)stream, "otter_vit_embed_lnpre");
+    return launch_ln<SRC_VIT, DT_F32, true>(a, (hipStream_t)stream, "otter_vit_embed_lnpre");
 }
 
 extern "C" int otter_text_embed(const int* ids, int ctx, int take, const float* token_embedding, int vocab,
@@ -158,5 +167,5 @@ extern "C" int otter_text_embed(const int* ids, int ctx, int take, const float* 
     LnArgs a{};
     a.x = token_embedding; a.ldx = width; a.y = x; a.ldy = ldx; a.rows = batch * take; a.width = width;
     a.pos = pos_embedding; a.ids = ids; a.ctx = ctx; a.take = take; a.vocab = vocab;
-    return launch_ln<SRC_TEXT, true, false>(a, (hipStream_t)stream, "otter_text_embed");
+    return launch_ln<SRC_TEXT, DT_F32, false>(a, (hipStream_t)stream, "otter_text_embed");
 }

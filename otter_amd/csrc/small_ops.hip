@@ -8,8 +8,8 @@ namespace {
 
 // ---------------------------------------------------------------- im2col (+ /255, (x-mean)/std for uint8 input)
 // out[(img*g*g + py*g + px)][c*ps*ps + ky*ps + kx] = norm(img[c][py*ps+ky][px*ps+kx]); columns >= 3*ps*ps are zero.
-template <bool U8>
-__global__ __launch_bounds__(256) void im2col_kernel(const void* images, __bf16* out, int res, int ps, int g, int kpad,
+template <bool U8, typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* images, T* out, int res, int ps, int g, int kpad,
                                                      float m0, float m1, float m2, float s0, float s1, float s2) {
     const int patch = blockIdx.x;                      // img*g*g + py*g + px
     const int img = patch / (g * g), py = (patch / g) % g, px = patch % g;
@@ -27,20 +27,21 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* images, __bf16*
                 v = ((const float*)images)[idx];
             }
         }
-        out[(long)patch * kpad + k] = f32_to_bf16(v);
+        out[(long)patch * kpad + k] = Half16<T>::from(v);
     }
 }
 
 // ---------------------------------------------------------------- y = x / ||x||_2 per row (fp32 in/out)
-__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, long ldx, float* y, long ldy, int rows, int width) {
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_kernel(const T* x, long ldx, float* y, long ldy, int rows, int width) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* src = x + (long)row * ldx;
+    const T* src = x + (long)row * ldx;
     float sq = 0.f;
-    for (int i = lane; i < width; i += 64) sq += src[i] * src[i];
+    for (int i = lane; i < width; i += 64) { const float v = (float)src[i]; sq += v * v; }
     const float rn = 1.0f / sqrtf(wave_sum(sq));
-    for (int i = lane; i < width; i += 64) y[(long)row * ldy + i] = src[i] * rn;
+    for (int i = lane; i < width; i += 64) y[(long)row * ldy + i] = (float)src[i] * rn;
 }
 
 // ---------------------------------------------------------------- y = act(x Wt + b), fp32, small shapes
@@ -78,16 +79,20 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, long ld
     }
 }
 
-// ---------------------------------------------------------------- fp32 -> bf16 with column zero-padding, optional row map
-// dst[r][c] = bf16(src[row_of(r)][c]) for c < cols, 0 for cols <= c < cols_pad.
+// ---------------------------------------------------------------- fp32 -> {bf16, fp16, fp32} row copy with zero-padding and row map
+// dst[r][c] = T(src[row_of(r)][c]) for c < cols, 0 for cols <= c < cols_pad.
 //   row_of(r) = r / rep                       (idx == null)
-//   row_of(r) = r * group + idx[r]            (idx != null: pick one row out of each group of `group` rows)
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, long lds_, __bf16* dst, long ldd, int rows, int cols,
-                                                        int cols_pad, int rep, const int* idx, int group) {
+//   row_of(r) = r * group + idx[r] + bias     (idx != null: pick one row out of each group of `group` rows)
+template <typename T> __device__ __forceinline__ T conv_out(float v) { return Half16<T>::from(v); }
+template <> __device__ __forceinline__ float conv_out<float>(float v) { return v; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void convert_rows_kernel(const float* src, long lds_, T* dst, long ldd, int rows, int cols,
+                                                           int cols_pad, int rep, const int* idx, int group, int bias) {
     const int row = blockIdx.x;
-    const long srow = idx ? (long)row * group + min(max(idx[row], 0), group - 1) : (long)(row / rep);
+    const long srow = idx ? (long)row * group + min(max(idx[row] + bias, 0), group - 1) : (long)(row / rep);
     for (int c = threadIdx.x; c < cols_pad; c += 256)
-        dst[(long)row * ldd + c] = f32_to_bf16(c < cols ? src[srow * lds_ + c] : 0.f);
+        dst[(long)row * ldd + c] = conv_out<T>(c < cols ? src[srow * lds_ + c] : 0.f);
 }
 
 // dst[r][0:cols] = src[r / rep][0:cols]   (fp32)
@@ -123,7 +128,18 @@ __global__ __launch_bounds__(256) void window_append_kernel(const float* src, co
 
 }  // namespace
 
-extern "C" int otter_im2col_patches(const void* images, int is_u8, void* out, int n_img, int res, int patch, int kpad,
+template <typename T>
+static void launch_im2col(const void* images, int is_u8, void* out, int n_img, int res, int patch, int g, int kpad,
+                          const float* mean3, const float* std3, hipStream_t s) {
+    if (is_u8)
+        hipLaunchKernelGGL((im2col_kernel<true, T>), dim3(n_img * g * g), dim3(256), 0, s, images, (T*)out, res, patch, g, kpad,
+                           mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    else
+        hipLaunchKernelGGL((im2col_kernel<false, T>), dim3(n_img * g * g), dim3(256), 0, s, images, (T*)out, res, patch, g, kpad,
+                           0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
+}
+
+extern "C" int otter_im2col_patches(int out_dtype, const void* images, int is_u8, void* out, int n_img, int res, int patch, int kpad,
                                     const float* mean3, const float* std3, void* stream) {
     OTTER_REQUIRE(images && out, OTTER_ERR_INVALID_ARGUMENT, "otter_im2col_patches: null operand");
     if (n_img == 0) return OTTER_OK;
@@ -133,24 +149,26 @@ extern "C" int otter_im2col_patches(const void* images, int is_u8, void* out, in
                   "otter_im2col_patches: kpad=%d must be a multiple of 64 and >= %d", kpad, 3 * patch * patch);
     const int g = res / patch;
     OTTER_REQUIRE((long)n_img * g * g < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_im2col_patches: grid too large");
+    OTTER_REQUIRE(out_dtype == DT_BF16 || out_dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_im2col_patches: out_dtype %d (bf16 or fp16)", out_dtype);
+    OTTER_REQUIRE(!is_u8 || (mean3 && std3), OTTER_ERR_INVALID_ARGUMENT, "otter_im2col_patches: uint8 input needs mean/std (host pointers)");
     hipStream_t s = (hipStream_t)stream;
-    if (is_u8) {
-        OTTER_REQUIRE(mean3 && std3, OTTER_ERR_INVALID_ARGUMENT, "otter_im2col_patches: uint8 input needs mean/std (host pointers)");
-        hipLaunchKernelGGL(im2col_kernel<true>, dim3(n_img * g * g), dim3(256), 0, s, images, (__bf16*)out, res, patch, g, kpad,
-                           mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
-    } else {
-        hipLaunchKernelGGL(im2col_kernel<false>, dim3(n_img * g * g), dim3(256), 0, s, images, (__bf16*)out, res, patch, g, kpad,
-                           0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
-    }
+    if (out_dtype == DT_BF16) launch_im2col<__bf16>(images, is_u8, out, n_img, res, patch, g, kpad, mean3, std3, s);
+    else launch_im2col<_Float16>(images, is_u8, out, n_img, res, patch, g, kpad, mean3, std3, s);
     OTTER_CHECK_LAUNCH("otter_im2col_patches");
     return OTTER_OK;
 }
 
-extern "C" int otter_l2norm_rows(const float* x, long ldx, float* y, long ldy, int rows, int width, void* stream) {
+extern "C" int otter_l2norm_rows(int x_dtype, const void* x, long ldx, float* y, long ldy, int rows, int width, void* stream) {
     OTTER_REQUIRE(x && y, OTTER_ERR_INVALID_ARGUMENT, "otter_l2norm_rows: null operand");
     if (rows == 0) return OTTER_OK;
     OTTER_REQUIRE(rows > 0 && width > 0 && ldx >= width && ldy >= width, OTTER_ERR_INVALID_ARGUMENT, "otter_l2norm_rows: bad sizes");
-    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, width);
+    OTTER_REQUIRE(x_dtype == DT_BF16 || x_dtype == DT_F16 || x_dtype == DT_F32, OTTER_ERR_INVALID_ARGUMENT, "otter_l2norm_rows: unknown dtype %d", x_dtype);
+    if (x_dtype == DT_BF16)
+        hipLaunchKernelGGL(l2norm_kernel<__bf16>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, ldx, y, ldy, rows, width);
+    else if (x_dtype == DT_F16)
+        hipLaunchKernelGGL(l2norm_kernel<_Float16>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, ldx, y, ldy, rows, width);
+    else
+        hipLaunchKernelGGL(l2norm_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, y, ldy, rows, width);
     OTTER_CHECK_LAUNCH("otter_l2norm_rows");
     return OTTER_OK;
 }
@@ -167,16 +185,25 @@ extern "C" int otter_linear_f32(const float* x, long ldx, const float* wt, const
     return OTTER_OK;
 }
 
-extern "C" int otter_cast_bf16(const float* src, long ld_src, void* dst, long ld_dst, int rows, int cols, int cols_pad,
-                               int rep, const int* pick, int group, void* stream) {
-    OTTER_REQUIRE(src && dst, OTTER_ERR_INVALID_ARGUMENT, "otter_cast_bf16: null operand");
+extern "C" int otter_convert_rows(int out_dtype, const float* src, long ld_src, void* dst, long ld_dst, int rows, int cols, int cols_pad,
+                                  int rep, const int* pick, int group, int pick_bias, void* stream) {
+    OTTER_REQUIRE(src && dst, OTTER_ERR_INVALID_ARGUMENT, "otter_convert_rows: null operand");
     if (rows == 0) return OTTER_OK;
     OTTER_REQUIRE(rows > 0 && cols > 0 && cols_pad >= cols && ld_src >= cols && ld_dst >= cols_pad && rep >= 1, OTTER_ERR_INVALID_ARGUMENT,
-                  "otter_cast_bf16: bad sizes");
-    OTTER_REQUIRE(!pick || group >= 1, OTTER_ERR_INVALID_ARGUMENT, "otter_cast_bf16: pick needs group >= 1");
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, src, ld_src, (__bf16*)dst, ld_dst, rows, cols,
-                       cols_pad, rep, pick, group);
-    OTTER_CHECK_LAUNCH("otter_cast_bf16");
+                  "otter_convert_rows: bad sizes");
+    OTTER_REQUIRE(!pick || group >= 1, OTTER_ERR_INVALID_ARGUMENT, "otter_convert_rows: pick needs group >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == DT_BF16)
+        hipLaunchKernelGGL(convert_rows_kernel<__bf16>, dim3(rows), dim3(256), 0, s, src, ld_src, (__bf16*)dst, ld_dst, rows, cols, cols_pad, rep, pick, group, pick_bias);
+    else if (out_dtype == DT_F16)
+        hipLaunchKernelGGL(convert_rows_kernel<_Float16>, dim3(rows), dim3(256), 0, s, src, ld_src, (_Float16*)dst, ld_dst, rows, cols, cols_pad, rep, pick, group, pick_bias);
+    else if (out_dtype == DT_F32)
+        hipLaunchKernelGGL(convert_rows_kernel<float>, dim3(rows), dim3(256), 0, s, src, ld_src, (float*)dst, ld_dst, rows, cols, cols_pad, rep, pick, group, pick_bias);
+    else {
+        otter_set_error("otter_convert_rows: unknown out_dtype %d", out_dtype);
+        return OTTER_ERR_INVALID_ARGUMENT;
+    }
+    OTTER_CHECK_LAUNCH("otter_convert_rows");
     return OTTER_OK;
 }
 

@@ -23,12 +23,11 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) short bf16x4_s;   // operand type of the 16x16x16 bf16 MFMA
-
 struct TaveArgs {
-    const __bf16* patches;      // [units][P][D]
+    const void* patches;        // unit u at patches + u*unit_stride, [P][D] row-major, bf16 or fp16
+    long unit_stride;
     const float* text;          // [n_text][K][D]
-    const __bf16* posT;         // [cams][D][P]  (pos_emb transposed, bf16)
+    const void* posT;           // [cams][D][P]  (pos_emb transposed, same 16-bit type as the patches)
     const float* temperature;   // [cams]
     float* out;                 // [cams][M][K][D]
     int units, cams, P, D, K, t_rep, M;
@@ -41,9 +40,11 @@ __device__ __forceinline__ int f_swz(int r) {
     return (((lo + 4 * hi) & 7) << 1) | hi;
 }
 
-template <int NDT>   // D = NDT * 64; each wave owns NDT d-tiles of 16 columns
+template <typename T, int NDT>   // D = NDT * 64; each wave owns NDT d-tiles of 16 columns
 __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Half16<T>::v8 v8;
+    typedef typename Half16<T>::v4 v4;
     constexpr int D = NDT * 64;
     constexpr int ROWB = D * 2;                 // bytes per LDS row
     constexpr int TILE_B = 16 * ROWB;           // one 16-row image
@@ -57,8 +58,8 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
     const int unit = blockIdx.x;
     const int m = unit / p.cams, cam = unit % p.cams;
     const int P = p.P, nt = P >> 4;
-    const __bf16* X = p.patches + (long)unit * P * D;
-    const __bf16* posT = p.posT + (long)cam * D * P;
+    const T* X = (const T*)p.patches + (long)unit * p.unit_stride;
+    const T* posT = (const T*)p.posT + (long)cam * D * P;
 
     // ---- per-lane LDS-DMA source offsets (bytes within a tile), identical for every tile ----
     int src_off[NLD];
@@ -98,11 +99,11 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
             for (int i = 0; i < (D / 4 + 63) / 64; ++i) {
                 const int idx = i * 64 + lane;           // 4-element group index
                 if (idx < D / 4) {
-                    bf16x4 o;
+                    v4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[i][e] * rn);
+                    for (int e = 0; e < 4; ++e) o[e] = Half16<T>::from(v[i][e] * rn);
                     const int chunk = idx >> 1;
-                    *(bf16x4*)(sT + r * ROWB + ((chunk ^ f_swz(r)) << 4) + (idx & 1) * 8) = o;
+                    *(v4*)(sT + r * ROWB + ((chunk ^ f_swz(r)) << 4) + (idx & 1) * 8) = o;
                 }
             }
         }
@@ -134,10 +135,10 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
 #pragma unroll 4
         for (int ks = 0; ks < D / 32; ++ks) {
             const int coff = (((ks * 4 + g) ^ fsw) << 4);
-            const bf16x8 xf = *(const bf16x8*)(xb + frag_row + coff);
-            const bf16x8 tf = *(const bf16x8*)(sT + frag_row + coff);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, tf, s, 0, 0, 0);
-            gd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, xf, gd, 0, 0, 0);
+            const v8 xf = *(const v8*)(xb + frag_row + coff);
+            const v8 tf = *(const v8*)(sT + frag_row + coff);
+            s = Half16<T>::mfma32(xf, tf, s);
+            gd = Half16<T>::mfma32(xf, xf, gd);
         }
         // |x|^2 of patch 4g+r sits on lane (g, li = 4g+r), register r
         float a1[4], a2[4];
@@ -156,16 +157,13 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
         const float alpha = __expf(run_max - new_max);     // first tile: exp(-inf) = 0
         run_max = new_max;
         float psum = 0.f;
-        bf16x4_s b1, b2;
+        s16x4 b1, b2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float pr = __expf(a2[r] - new_max);
             psum += pr;
-            union { __bf16 h; short s; } c1, c2;
-            c1.h = f32_to_bf16(pr * a1[r]);
-            c2.h = f32_to_bf16(pr);
-            b1[r] = c1.s;
-            b2[r] = c2.s;
+            b1[r] = bits16(Half16<T>::from(pr * a1[r]));
+            b2[r] = bits16(Half16<T>::from(pr));
         }
         run_sum = run_sum * alpha + psum;                   // per-lane partial (its own 4 patches per tile)
 #pragma unroll
@@ -178,9 +176,9 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
             const int chunk = (d0 >> 3) + ((li & 3) >> 1);
             const s16x4 xt = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4*)(xb + tr_row * ROWB + ((chunk ^ tr_fsw) << 4) + tr_sub));
-            const bf16x4_s pt = *(const bf16x4_s*)(posT + (long)(d0 + li) * P + t * 16 + 4 * g);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt, b1, o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pt, b2, o[dt], 0, 0, 0);
+            const s16x4 pt = *(const s16x4*)(posT + (long)(d0 + li) * P + t * 16 + 4 * g);
+            o[dt] = Half16<T>::mfma16(xt, b1, o[dt]);
+            o[dt] = Half16<T>::mfma16(pt, b2, o[dt]);
         }
         __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done with this buffer
     }
@@ -198,10 +196,10 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
     }
 }
 
-template <int NDT>
+template <typename T, int NDT>
 int launch_tave(const TaveArgs& a, hipStream_t s) {
     constexpr int lds = 3 * 16 * NDT * 64 * 2;
-    auto kern = tave_kernel<NDT>;
+    auto kern = tave_kernel<T, NDT>;
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -212,18 +210,32 @@ int launch_tave(const TaveArgs& a, hipStream_t s) {
     return OTTER_OK;
 }
 
-__global__ void pos_transpose_kernel(const float* pos, __bf16* posT, int P, int D) {
-    // posT[d][k] = bf16(pos[k][d]); one thread per output element (setup-time kernel)
+template <typename T>
+__global__ void pos_transpose_kernel(const float* pos, T* posT, int P, int D) {
+    // posT[d][k] = T(pos[k][d]); one thread per output element (setup-time kernel)
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)P * D) return;
     const int d = (int)(i / P), k = (int)(i % P);
-    posT[i] = f32_to_bf16(pos[(long)k * D + d]);
+    posT[i] = Half16<T>::from(pos[(long)k * D + d]);
+}
+
+template <typename T>
+int dispatch_tave(const TaveArgs& a, int D, hipStream_t s) {
+    switch (D) {
+        case 128: return launch_tave<T, 2>(a, s);
+        case 512: return launch_tave<T, 8>(a, s);
+        case 768: return launch_tave<T, 12>(a, s);
+        case 1024: return launch_tave<T, 16>(a, s);
+    }
+    otter_set_error("otter_text_aware_pool_fwd: D=%d unsupported (128, 512, 768, 1024)", D);
+    return OTTER_ERR_UNSUPPORTED_SHAPE;
 }
 
 }  // namespace
 
-extern "C" int otter_text_aware_pool_fwd(const void* patches, const float* text, const void* posT, const float* temperature,
+extern "C" int otter_text_aware_pool_fwd(int dtype, const void* patches, long unit_stride, const float* text, const void* posT, const float* temperature,
                                          float* out, int n_obs, int cams, int P, int D, int K, int t_rep, void* stream) {
+    OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: dtype %d (bf16 or fp16)", dtype);
     OTTER_REQUIRE(patches && text && posT && temperature && out, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: null operand");
     if (n_obs == 0) return OTTER_OK;
     OTTER_REQUIRE(n_obs > 0 && cams > 0 && t_rep > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: bad sizes");
@@ -233,23 +245,21 @@ extern "C" int otter_text_aware_pool_fwd(const void* patches, const float* text,
     OTTER_REQUIRE(aligned16(patches) && aligned16(text) && aligned16(posT) && aligned16(out), OTTER_ERR_ALIGNMENT,
                   "otter_text_aware_pool_fwd: operands must be 16-byte aligned");
     OTTER_REQUIRE((long)n_obs * cams < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_fwd: grid too large");
-    TaveArgs a{(const __bf16*)patches, text, (const __bf16*)posT, temperature, out, n_obs * cams, cams, P, D, K, t_rep, n_obs};
+    OTTER_REQUIRE(unit_stride >= (long)P * D && unit_stride % 8 == 0, OTTER_ERR_ALIGNMENT,
+                  "otter_text_aware_pool_fwd: unit_stride=%ld must be >= P*D and a multiple of 8 elements", unit_stride);
+    TaveArgs a{patches, unit_stride, text, posT, temperature, out, n_obs * cams, cams, P, D, K, t_rep, n_obs};
     hipStream_t s = (hipStream_t)stream;
-    switch (D) {
-        case 128: return launch_tave<2>(a, s);
-        case 512: return launch_tave<8>(a, s);
-        case 768: return launch_tave<12>(a, s);
-        case 1024: return launch_tave<16>(a, s);
-    }
-    otter_set_error("otter_text_aware_pool_fwd: D=%d unsupported (128, 512, 768, 1024)", D);
-    return OTTER_ERR_UNSUPPORTED_SHAPE;
+    return dtype == DT_BF16 ? dispatch_tave<__bf16>(a, D, s) : dispatch_tave<_Float16>(a, D, s);
 }
 
-extern "C" int otter_pos_emb_transpose(const float* pos, void* posT, int P, int D, void* stream) {
+extern "C" int otter_pos_emb_transpose(int dtype, const float* pos, void* posT, int P, int D, void* stream) {
+    OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_pos_emb_transpose: dtype %d (bf16 or fp16)", dtype);
     OTTER_REQUIRE(pos && posT && P > 0 && D > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_pos_emb_transpose: bad arguments");
     const long n = (long)P * D;
-    hipLaunchKernelGGL(pos_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       pos, (__bf16*)posT, P, D);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(pos_transpose_kernel<__bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (__bf16*)posT, P, D);
+    else
+        hipLaunchKernelGGL(pos_transpose_kernel<_Float16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (_Float16*)posT, P, D);
     OTTER_CHECK_LAUNCH("otter_pos_emb_transpose");
     return OTTER_OK;
 }

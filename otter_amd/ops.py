@@ -12,11 +12,24 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, OUT_F32, RESIDUAL, OtterHipError, ReadoutBlock  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, DT_BF16, DT_F16, DT_F32, OUT_F32, RESIDUAL,  # noqa: F401
+                   OtterHipError, ReadoutBlock)
 
 Tensor = torch.Tensor
 GEMM_N_ALIGN = 128
-GEMM_K_ALIGN = 64
+GEMM_K_BYTES = 128          # a K-step of the GEMM is 128 bytes per row: 64 halves or 32 floats
+
+DT = {torch.bfloat16: DT_BF16, torch.float16: DT_F16, torch.float32: DT_F32}
+
+
+def k_align(dtype) -> int:
+    return GEMM_K_BYTES // torch.empty((), dtype=dtype).element_size()
+
+
+def _dt(dtype, name: str, allow_f32: bool = True) -> int:
+    if dtype not in DT or (dtype == torch.float32 and not allow_f32):
+        raise TypeError(f"{name}: unsupported dtype {dtype}")
+    return DT[dtype]
 
 
 def _stream() -> ctypes.c_void_p:
@@ -54,11 +67,11 @@ def round_up(x: int, m: int) -> int:
 
 # ----------------------------------------------------------------------------------------- weight packing
 
-def pack_weight(w: Tensor, device=None) -> Tensor:
-    """torch Linear weight (N, K) fp32 -> bf16 (N rounded up to 128, K rounded up to 64), zero padded."""
+def pack_weight(w: Tensor, dtype=torch.bfloat16, device=None) -> Tensor:
+    """torch Linear weight (N, K) -> ``dtype`` (N rounded up to 128, K rounded up to the GEMM's K-step), zero padded."""
     n, k = w.shape
-    out = torch.zeros(round_up(n, GEMM_N_ALIGN), round_up(k, GEMM_K_ALIGN), dtype=torch.bfloat16, device=device or w.device)
-    out[:n, :k] = w.to(device=out.device, dtype=torch.bfloat16)
+    out = torch.zeros(round_up(n, GEMM_N_ALIGN), round_up(k, k_align(dtype)), dtype=dtype, device=device or w.device)
+    out[:n, :k] = w.to(device=out.device, dtype=dtype)
     return out
 
 
@@ -66,9 +79,11 @@ def pack_weight(w: Tensor, device=None) -> Tensor:
 
 def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
          out_f32: bool = False, residual: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
-    """out[M, n] = epilogue(a[M, K] @ w[n, K]^T + bias); ``w_packed`` from :func:`pack_weight`."""
-    _chk(a, torch.bfloat16, "gemm.a")
-    _chk(w_packed, torch.bfloat16, "gemm.w", 2)
+    """out[M, n] = epilogue(a[M, K] @ w[n, K]^T + bias); operands bf16 / fp16 / fp32 (``w_packed`` from
+    :func:`pack_weight` with the same dtype); output the operand type, or fp32 (``out_f32``, residual, fp32 operands)."""
+    dt = _dt(a.dtype, "gemm.a")
+    _chk(a, a.dtype, "gemm.a")
+    _chk(w_packed, a.dtype, "gemm.w", 2)
     m, k, lda = _rows_view(a, "gemm.a")
     if not w_packed.is_contiguous() or w_packed.shape[1] != k:
         raise ValueError(f"gemm: weight {tuple(w_packed.shape)} does not match K={k} (activations must carry the padded K)")
@@ -78,8 +93,9 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         _chk(bias, torch.float32, "gemm.bias", 1)
         if bias.numel() < n:
             raise ValueError("gemm: bias shorter than N")
-    epi = act | (OUT_F32 if (out_f32 or residual is not None) else 0) | (RESIDUAL if residual is not None else 0)
-    odt = torch.float32 if (epi & OUT_F32) else torch.bfloat16
+    f32_out = out_f32 or residual is not None or a.dtype == torch.float32
+    epi = act | (OUT_F32 if f32_out else 0) | (RESIDUAL if residual is not None else 0)
+    odt = torch.float32 if f32_out else a.dtype
     if out is None:
         out = torch.empty(m, n, dtype=odt, device=a.device)
     _chk(out, odt, "gemm.out")
@@ -94,13 +110,13 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
             raise ValueError("gemm: residual shape mismatch")
     if m == 0:
         return out
-    _lib.call("otter_gemm_bf16", _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
+    _lib.call("otter_gemm", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
               _ptr(out), ldc, m, n, k, epi, _stream())
     return out
 
 
-def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], *, eps: float = 1e-5, out_f32: bool = False,
-              out: Optional[Tensor] = None) -> Tensor:
+def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], *, eps: float = 1e-5,
+              out_dtype=torch.bfloat16, out: Optional[Tensor] = None) -> Tensor:
     _chk(x, torch.float32, "layernorm.x")
     rows, width, ldx = _rows_view(x, "layernorm.x")
     for t, nm in ((gamma, "gamma"), (beta, "beta")):
@@ -108,14 +124,15 @@ def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], *, eps
             _chk(t, torch.float32, "layernorm." + nm, 1)
             if t.numel() != width:
                 raise ValueError(f"layernorm.{nm}: {t.numel()} elements, expected {width}")
-    odt = torch.float32 if out_f32 else torch.bfloat16
+    odt = out_dtype
+    dt = _dt(odt, "layernorm.out_dtype")
     if out is None:
         out = torch.empty(rows, width, dtype=odt, device=x.device)
     _chk(out, odt, "layernorm.out")
     ro, wo, ldy = _rows_view(out, "layernorm.out")
     if ro != rows or wo != width:
         raise ValueError("layernorm: out shape mismatch")
-    _lib.call("otter_layernorm", _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(out), ldy, rows, width, eps, int(out_f32), _stream())
+    _lib.call("otter_layernorm", _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(out), ldy, rows, width, eps, dt, _stream())
     return out
 
 
@@ -156,8 +173,9 @@ def text_embed(ids: Tensor, take: int, token_embedding: Tensor, pos: Tensor) -> 
     return x
 
 
-def im2col_patches(images: Tensor, patch: int, kpad: int, mean: Sequence[float], std: Sequence[float]) -> Tensor:
-    """images (N, 3, R, R) uint8 (normalisation fused) or float32 (already normalised) -> bf16 (N*g*g, kpad)."""
+def im2col_patches(images: Tensor, patch: int, kpad: int, mean: Sequence[float], std: Sequence[float],
+                   out_dtype=torch.bfloat16) -> Tensor:
+    """images (N, 3, R, R) uint8 (normalisation fused) or float32 (already normalised) -> bf16/fp16 (N*g*g, kpad)."""
     if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != images.shape[3]:
         raise ValueError(f"im2col: expected (N, 3, R, R), got {tuple(images.shape)}")
     if images.dtype not in (torch.uint8, torch.float32):
@@ -167,25 +185,26 @@ def im2col_patches(images: Tensor, patch: int, kpad: int, mean: Sequence[float],
         raise ValueError("im2col: images must be contiguous")
     n, _, res, _ = images.shape
     g = res // patch
-    out = torch.empty(n * g * g, kpad, dtype=torch.bfloat16, device=images.device)
+    out = torch.empty(n * g * g, kpad, dtype=out_dtype, device=images.device)
     m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
-    _lib.call("otter_im2col_patches", _ptr(images), int(images.dtype == torch.uint8), _ptr(out), n, res, patch, kpad, m3, s3, _stream())
+    _lib.call("otter_im2col_patches", _dt(out_dtype, "im2col.out_dtype", False), _ptr(images), int(images.dtype == torch.uint8), _ptr(out), n, res, patch, kpad, m3, s3, _stream())
     return out
 
 
 def attn_d64(qkv: Tensor, n_seq: int, seq_len: int, heads: int, causal: bool) -> Tensor:
-    _chk(qkv, torch.bfloat16, "attn.qkv", 2)
+    dt = _dt(qkv.dtype, "attn.qkv", False)
+    _chk(qkv, qkv.dtype, "attn.qkv", 2)
     rows, width, ld = _rows_view(qkv, "attn.qkv")
     if rows != n_seq * seq_len or width != 3 * heads * 64:
         raise ValueError(f"attn: qkv {tuple(qkv.shape)} does not match n_seq={n_seq} L={seq_len} heads={heads}")
-    out = torch.empty(rows, heads * 64, dtype=torch.bfloat16, device=qkv.device)
-    _lib.call("otter_attn_fwd_d64", _ptr(qkv), ld, _ptr(out), heads * 64, n_seq, seq_len, heads, int(causal), _stream())
+    out = torch.empty(rows, heads * 64, dtype=qkv.dtype, device=qkv.device)
+    _lib.call("otter_attn_fwd_d64", dt, _ptr(qkv), ld, _ptr(out), heads * 64, n_seq, seq_len, heads, int(causal), _stream())
     return out
 
 
 def attn_policy(qkv_cache: Tensor, n_query: int, pos0: int, heads: int) -> Tensor:
-    """qkv_cache (B, S, 3*dim) fp32 -> bf16 (B*n_query, dim)."""
+    """qkv_cache (B, S, 3*dim) fp32 -> fp32 (B*n_query, dim)."""
     _chk(qkv_cache, torch.float32, "attn_policy.qkv", 3)
     if not qkv_cache.is_contiguous():
         raise ValueError("attn_policy: cache must be contiguous")
@@ -195,30 +214,38 @@ def attn_policy(qkv_cache: Tensor, n_query: int, pos0: int, heads: int) -> Tenso
         raise ValueError("attn_policy: bad cache width")
     if pos0 < 0 or pos0 + n_query > s:
         raise ValueError(f"attn_policy: positions {pos0}..{pos0 + n_query - 1} outside window {s}")
-    out = torch.empty(b * n_query, dim, dtype=torch.bfloat16, device=qkv_cache.device)
+    out = torch.empty(b * n_query, dim, dtype=torch.float32, device=qkv_cache.device)
     _lib.call("otter_attn_policy", _ptr(qkv_cache), w3, _ptr(out), dim, b, s, n_query, pos0, heads, dim // heads, _stream())
     return out
 
 
-def pos_emb_transpose(pos: Tensor) -> Tensor:
+def pos_emb_transpose(pos: Tensor, dtype=torch.bfloat16) -> Tensor:
     _chk(pos, torch.float32, "pos_emb", 2)
     if not pos.is_contiguous():
         raise ValueError("pos_emb must be contiguous")
     p, d = pos.shape
-    out = torch.empty(d, p, dtype=torch.bfloat16, device=pos.device)
-    _lib.call("otter_pos_emb_transpose", _ptr(pos), _ptr(out), p, d, _stream())
+    out = torch.empty(d, p, dtype=dtype, device=pos.device)
+    _lib.call("otter_pos_emb_transpose", _dt(dtype, "pos_emb.dtype", False), _ptr(pos), _ptr(out), p, d, _stream())
     return out
 
 
-def text_aware_pool(patches: Tensor, text: Tensor, pos_t: Tensor, temperature: Tensor, n_obs: int, cams: int, t_rep: int) -> Tensor:
-    """patches bf16 (n_obs*cams, P, D); text fp32 (n_obs/t_rep, K, D); pos_t bf16 (cams, D, P); -> fp32 (cams, n_obs, K, D)."""
-    _chk(patches, torch.bfloat16, "tave.patches", 3)
+def text_aware_pool(patches: Tensor, text: Tensor, pos_t: Tensor, temperature: Tensor, n_obs: int, cams: int, t_rep: int,
+                    n_patches: Optional[int] = None) -> Tensor:
+    """Fused text-aware visual extraction.
+
+    patches bf16/fp16: either (n_obs*cams, P, D) contiguous, or (n_obs*cams, L, D) with ``n_patches`` = P < L given,
+    in which case the LAST P rows of each unit are used (skips the class token of a ViT output);
+    text fp32 (n_obs/t_rep, K, D); pos_t (cams, D, P) of the patches' dtype; -> fp32 (cams, n_obs, K, D).
+    """
+    dt = _dt(patches.dtype, "tave.patches", False)
+    _chk(patches, patches.dtype, "tave.patches", 3)
     _chk(text, torch.float32, "tave.text", 3)
-    _chk(pos_t, torch.bfloat16, "tave.posT", 3)
+    _chk(pos_t, patches.dtype, "tave.posT", 3)
     _chk(temperature, torch.float32, "tave.temperature", 1)
-    units, p, d = patches.shape
+    units, rows, d = patches.shape
+    p = n_patches if n_patches is not None else rows
     nt, k, d2 = text.shape
-    if units != n_obs * cams or d2 != d or n_obs % t_rep != 0 or nt != n_obs // t_rep:
+    if units != n_obs * cams or d2 != d or n_obs % t_rep != 0 or nt != n_obs // t_rep or p > rows:
         raise ValueError(f"tave: patches {tuple(patches.shape)}, text {tuple(text.shape)}, n_obs={n_obs}, cams={cams}, t_rep={t_rep}")
     if tuple(pos_t.shape) != (cams, d, p) or temperature.numel() != cams:
         raise ValueError("tave: pos_t / temperature shape mismatch")
@@ -226,7 +253,8 @@ def text_aware_pool(patches: Tensor, text: Tensor, pos_t: Tensor, temperature: T
         if not t.is_contiguous():
             raise ValueError("tave: operands must be contiguous")
     out = torch.empty(cams, n_obs, k, d, dtype=torch.float32, device=patches.device)
-    _lib.call("otter_text_aware_pool_fwd", _ptr(patches), _ptr(text), _ptr(pos_t), _ptr(temperature), _ptr(out), n_obs, cams,
+    base = ctypes.c_void_p(patches.data_ptr() + (rows - p) * d * 2)
+    _lib.call("otter_text_aware_pool_fwd", dt, base, rows * d, _ptr(text), _ptr(pos_t), _ptr(temperature), _ptr(out), n_obs, cams,
               p, d, k, t_rep, _stream())
     return out
 
@@ -256,10 +284,12 @@ def readout_pool(blocks, query: Tensor, final_w: Tensor, final_b: Tensor, kv: Te
 
 
 def l2norm_rows(x: Tensor) -> Tensor:
-    _chk(x, torch.float32, "l2norm.x", 2)
+    """fp32 / bf16 / fp16 (rows, width) -> fp32 rows of unit L2 norm."""
+    dt = _dt(x.dtype, "l2norm.x")
+    _chk(x, x.dtype, "l2norm.x", 2)
     rows, width, ldx = _rows_view(x, "l2norm.x")
     y = torch.empty(rows, width, dtype=torch.float32, device=x.device)
-    _lib.call("otter_l2norm_rows", _ptr(x), ldx, _ptr(y), width, rows, width, _stream())
+    _lib.call("otter_l2norm_rows", dt, _ptr(x), ldx, _ptr(y), width, rows, width, _stream())
     return y
 
 
@@ -285,9 +315,9 @@ def linear_f32(x: Tensor, wt: Tensor, bias: Optional[Tensor], act: int = ACT_NON
     return out
 
 
-def cast_bf16(src: Tensor, cols_pad: Optional[int] = None, rep: int = 1, pick: Optional[Tensor] = None, group: int = 1,
-              rows: Optional[int] = None) -> Tensor:
-    """fp32 (R, C) -> bf16 (rows, cols_pad); see ``otter_cast_bf16`` for the row maps."""
+def convert_rows(src: Tensor, out_dtype=torch.float32, cols_pad: Optional[int] = None, rep: int = 1,
+                 pick: Optional[Tensor] = None, group: int = 1, rows: Optional[int] = None, pick_bias: int = 0) -> Tensor:
+    """fp32 (R, C) -> ``out_dtype`` (rows, cols_pad); see ``otter_convert_rows`` for the row maps."""
     _chk(src, torch.float32, "cast.src", 2)
     r, c, lds = _rows_view(src, "cast.src")
     cols_pad = cols_pad or c
@@ -300,8 +330,8 @@ def cast_bf16(src: Tensor, cols_pad: Optional[int] = None, rep: int = 1, pick: O
         n_rows = rows if rows is not None else r * rep
         if (n_rows - 1) // rep >= r:
             raise ValueError("cast: rep maps past the source rows")
-    dst = torch.empty(n_rows, cols_pad, dtype=torch.bfloat16, device=src.device)
-    _lib.call("otter_cast_bf16", _ptr(src), lds, _ptr(dst), cols_pad, n_rows, c, cols_pad, rep, _ptr(pick), group, _stream())
+    dst = torch.empty(n_rows, cols_pad, dtype=out_dtype, device=src.device)
+    _lib.call("otter_convert_rows", _dt(out_dtype, "convert.out_dtype"), _ptr(src), lds, _ptr(dst), cols_pad, n_rows, c, cols_pad, rep, _ptr(pick), group, pick_bias, _stream())
     return dst
 
 

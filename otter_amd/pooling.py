@@ -1,7 +1,7 @@
 """Device-side AttentionPooling (``otter/policy/transformer.py:162-232``).
 
 The only part with real FLOPs -- projecting the (n_obs*nk) key/value tokens from D_in to d for every block --
-runs as ONE bf16 MFMA GEMM: the tokens are normalised once (no affine) and each block's ``kv_layer_norm``
+runs as ONE fp32 MFMA GEMM: the tokens are normalised once (no affine) and each block's ``kv_layer_norm``
 affine is folded into its projection weights (W' = W diag(gamma), b' = W beta + b), the K and V weights of all
 blocks are stacked along N.  The query side runs in the fp32 readout kernel.
 """
@@ -58,13 +58,13 @@ class PoolingWeights:
         self.hidden = sd[prefix + "blocks.0.mlp.fc1.weight"].shape[0]
         self.d_in = ws[0].shape[1]
         self.kv_n = 2 * d * n
-        self.kv_w = ops.pack_weight(torch.cat(ws, 0))
+        self.kv_w = ops.pack_weight(torch.cat(ws, 0), torch.float32)
         self.kv_b = torch.cat(bs, 0).contiguous()
         self.blocks = blocks
 
     def forward(self, x: Tensor, mask: Optional[Tensor], out: Tensor, n_obs: int, nk: int) -> Tensor:
         """x fp32 (n_obs*nk, D_in); mask bool/uint8 (n_obs, nk) with True = ignore; out fp32 view (n_obs, readouts*d)."""
-        xn = ops.layernorm(x, None, None)
+        xn = ops.layernorm(x, None, None, out_dtype=torch.float32)
         kv = ops.gemm(xn, self.kv_w, self.kv_n, self.kv_b, out_f32=True)
         m8 = None
         if mask is not None:

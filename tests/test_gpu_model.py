@@ -1,0 +1,150 @@
+"""Whole-path parity on the GPU: the HIP OTTER model against (a) the fixtures produced by the reference's own
+OTTER class (tiny CLIP) and (b) the fp32 CPU oracle at the full default configuration (ViT-L/14).
+
+Tolerances come from the task statement: visual tokens cosine >= 0.9999, actions within 1e-3 abs of fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+from oracle import clip_ref
+from oracle import otter_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from otter_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _model(mc, sc, seed, dev):
+    from otter_amd.otter import OTTER
+    from otter_amd.params import otter_specs, random_state_dict
+    sd = random_state_dict(otter_specs(mc, sc), seed=seed)
+    model = OTTER(mc, sc)
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev).eval(), sd
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm()))
+
+
+@pytest.mark.parametrize("case", GI.E2E_CASES, ids=lambda c: c["name"])
+def test_tiny_model_matches_reference_fixtures(dev, golden, case):
+    g = golden("otter_e2e")
+    n = case["name"]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    np.testing.assert_allclose(GI.sd_probe(sd), g[n + "__sd_probe"], rtol=1e-12)
+    images, text, proprio, gt = GI.e2e_inputs(case)
+
+    pf, tf = model.extract_clip_features(images.to(dev), text)
+    ref_pf = torch.from_numpy(g[n + "__patch_feat_cam0_first"])
+    assert _cos(pf[0][0, :4].cpu(), ref_pf) >= 0.9999
+    assert _cos(tf[0].cpu(), torch.from_numpy(g[n + "__text_feat_first"])) >= 0.9999
+
+    enc = model.forward_encoder(images.to(dev), text, proprio.to(dev),
+                                R.create_text_mask(text, 49406, 49407, mc.first_k_tokens) if mc.pool_true_text else None)
+    ref_enc = torch.from_numpy(g[n + "__encoder"])
+    assert _cos(enc.cpu(), ref_enc) >= 0.9999
+
+    actions = model(images.to(dev), text, proprio.to(dev)).cpu()
+    ref_actions = torch.from_numpy(g[n + "__actions"])
+    assert actions.shape == ref_actions.shape
+    err = (actions - ref_actions).abs().max().item()
+    print(f"{n}: max |action - ref| = {err:.2e}, |ref| max = {ref_actions.abs().max():.3f}")
+    assert err <= 1e-3
+
+    loss = model(images.to(dev), text, proprio.to(dev), gt.to(dev)).item()
+    assert abs(loss - float(g[n + "__loss"])) <= 1e-3
+
+    # rollout through the window boundary: cached steps while the window fills, recompute after it slides
+    r_images, r_text, r_proprio = GI.rollout_inputs(case)
+    mask = R.create_text_mask(r_text, 49406, 49407, mc.first_k_tokens) if mc.pool_true_text else None
+    model.reset_cache()
+    ref_steps = g[n + "__rollout"]
+    worst = 0.0
+    for t in range(r_images.shape[0]):
+        a = model.forward_inference(r_images[t].to(dev), r_text, r_proprio[t].to(dev), mask).cpu().numpy()
+        assert model.cache_size == min(t + 1, sc.seq_length)
+        assert model.cached_transformer_input.shape[1] == model.cache_size
+        worst = max(worst, float(np.abs(a - ref_steps[t]).max()))
+    print(f"{n}: rollout max |action - ref| = {worst:.2e}")
+    assert worst <= 1e-3
+    model.reset_cache()
+    assert model.cache_size == 0 and model.cached_transformer_input is None
+    a0 = model.forward_inference(r_images[0].to(dev), r_text, r_proprio[0].to(dev), mask).cpu().numpy()
+    assert float(np.abs(a0 - ref_steps[0]).max()) <= 1e-3
+
+
+def test_default_config_vit_l14_matches_oracle(dev):
+    """Random-init default configuration (the reference's tests/test_dummy_model.py set-up), batch 1, two 224^2
+    cameras, one prompt: visual tokens, text tokens, policy input and actions against the fp32 CPU oracle."""
+    from otter_amd.config import ModelConfig, SharedConfig
+    mc, sc = ModelConfig(), SharedConfig()
+    model, sd = _model(mc, sc, 0, dev)
+    dims = R.Dims()
+    rng = np.random.default_rng(5)
+    steps = 3
+    images = torch.from_numpy(rng.integers(0, 256, (steps, 2, 3, 224, 224), dtype=np.uint8))
+    text = torch.zeros(77, dtype=torch.int32)
+    ids = rng.integers(1, 49406, 6)
+    text[0], text[1:7], text[7] = 49406, torch.from_numpy(ids.astype(np.int32)), 49407
+    proprio = torch.from_numpy(rng.standard_normal((steps, 10)).astype(np.float32))
+
+    # visual / text tokens of the first observation
+    pf, tf = model.extract_clip_features(images[:1, None].to(dev), text[None])
+    with torch.no_grad():
+        ref_pf = clip_ref.patch_features(R.clip_transform(images[0]), sd)
+        ref_tf = clip_ref.text_features(text[None], 15, sd)
+    cos_patch = min(_cos(pf[c][0].cpu(), ref_pf[c]) for c in range(2))
+    worst_tok = min(_cos(pf[c][0, i].cpu(), ref_pf[c, i]) for c in range(2) for i in range(0, 256, 17))
+    cos_text = _cos(tf[0].cpu(), ref_tf[0])
+    print(f"ViT-L/14: patch cosine {cos_patch:.6f} (worst sampled token {worst_tok:.6f}), text cosine {cos_text:.6f}")
+    assert cos_patch >= 0.9999 and worst_tok >= 0.9999 and cos_text >= 0.9999
+
+    ro = R.Rollout(sd, dims)
+    model.reset_cache()
+    worst = 0.0
+    for t in range(steps):
+        ref = ro.step(R.clip_transform(images[t]), text, proprio[t]).numpy()
+        got = model.forward_inference(images[t].to(dev), text, proprio[t].to(dev)).cpu().numpy()
+        worst = max(worst, float(np.abs(got - ref).max()))
+        print(f"step {t}: max |action - oracle| = {np.abs(got - ref).max():.2e}  (|oracle| max {np.abs(ref).max():.3f})")
+    assert worst <= 1e-3
+
+
+def test_batched_rollout_equals_single_episode(dev):
+    """B concurrent episodes give each episode what it gets alone; a per-episode reset does not disturb the others."""
+    from otter_amd.engine import BatchedRollout
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    d = model.device_model()
+    B, steps = 3, sc.seq_length + 3
+    rng = np.random.default_rng(9)
+    images = torch.from_numpy(rng.integers(0, 256, (steps, B, 2, 3, 112, 112), dtype=np.uint8)).to(dev)
+    proprio = torch.from_numpy(rng.standard_normal((steps, B, 10)).astype(np.float32)).to(dev)
+    text = GI._tokens(rng, B, (4, 7, 9))
+    tf = d.clip.text_tokens_cached(text)
+    batch = BatchedRollout(d, B)
+    got = [batch.step(images[t].reshape(B * 2, 3, 112, 112), tf, proprio[t]).cpu() for t in range(steps)]
+    for e in range(B):
+        single = BatchedRollout(d, 1)
+        for t in range(steps):
+            a = single.step(images[t, e], tf[e:e + 1], proprio[t, e:e + 1]).cpu()
+            torch.testing.assert_close(a[0], got[t][e], rtol=1e-3, atol=2e-4)
+    # reset episode 1 only: it restarts, the others continue
+    batch.reset([1])
+    nxt = batch.step(images[0].reshape(B * 2, 3, 112, 112), tf, proprio[0]).cpu()
+    fresh = BatchedRollout(d, 1)
+    torch.testing.assert_close(nxt[1], fresh.step(images[0, 1], tf[1:2], proprio[0, 1:2]).cpu()[0], rtol=1e-3, atol=2e-4)
+    assert list(batch.lens_host) == [sc.seq_length, 1, sc.seq_length]

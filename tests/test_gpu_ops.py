@@ -41,27 +41,40 @@ def _act(name, x):
 ACTS = {"none": 0, "quickgelu": 1, "gelu": 2, "relu": 3}
 
 
+DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
 @pytest.mark.parametrize("m,n,k", [(300, 256, 128), (1000, 3072, 1024), (129, 120, 1536), (5, 768, 704), (2056, 1024, 4096),
-                                   (1, 128, 64)])
+                                   (1, 128, 64), (64, 2304, 768)])
 @pytest.mark.parametrize("act", ["none", "quickgelu", "gelu", "relu"])
 @pytest.mark.parametrize("out_f32", [False, True])
-def test_gemm(dev, m, n, k, act, out_f32):
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+def test_gemm(dev, m, n, k, act, out_f32, dtype):
     from otter_amd import ops
-    a = _randn(1, m, k).to(dev).bfloat16()
+    dt = DTYPES[dtype]
+    if dtype == "f32" and not out_f32:
+        pytest.skip("fp32 operands always write fp32")
+    a = _randn(1, m, k).to(dev).to(dt)
     w = (_randn(2, n, k) / math.sqrt(k)).to(dev)
     bias = _randn(3, n).to(dev)
-    wp = ops.pack_weight(w)
+    wp = ops.pack_weight(w, dt)
     kp = wp.shape[1]
     if kp != k:
-        a_p = torch.zeros(m, kp, dtype=torch.bfloat16, device=dev)
+        a_p = torch.zeros(m, kp, dtype=dt, device=dev)
         a_p[:, :k] = a
     else:
         a_p = a
     out = ops.gemm(a_p, wp, n, bias, act=ACTS[act], out_f32=out_f32)
-    ref = _act(act, a.float() @ w.bfloat16().float().t() + bias)
+    ref = _act(act, a.double() @ w.to(dt).double().t() + bias.double()).float()
     assert out.shape == (m, n)
-    # fp32 accumulation of exact bf16 products: error is summation order only; bf16 output adds 2^-9 relative
-    tol = dict(rtol=2e-3, atol=2e-3) if out_f32 else dict(rtol=1e-2, atol=1e-2)
+    if dtype == "f32":
+        # exact fp32 fma chain in a different summation order than the fp64 reference: ~1e-6 relative to sum |a||w|
+        tol = dict(rtol=2e-5, atol=2e-5)
+    elif out_f32:
+        # fp32 accumulation of exact 16-bit products: summation order only
+        tol = dict(rtol=2e-3, atol=2e-3)
+    else:
+        tol = dict(rtol=1e-2, atol=1e-2) if dtype == "bf16" else dict(rtol=2e-3, atol=2e-3)   # output rounding 2^-9 / 2^-12
     torch.testing.assert_close(out.float(), ref, **tol)
 
 
@@ -75,7 +88,7 @@ def test_gemm_residual_strided_inplace(dev):
     bias = _randn(6, n).to(dev)
     res = _randn(7, m, n).to(dev)
     ref = a.float() @ w.bfloat16().float().t() + bias + res
-    out = ops.gemm(a, ops.pack_weight(w), n, bias, residual=res, out=res)      # in place on the residual stream
+    out = ops.gemm(a, ops.pack_weight(w), n, bias, residual=res, out=res)      # in place on the residual stream (bf16 operands)
     assert out.data_ptr() == res.data_ptr()
     torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-3)
     # rows of an output with a larger leading dimension stay untouched outside [0, n)
@@ -92,20 +105,22 @@ def test_gemm_rejects_bad_arguments(dev):
         ops.gemm(a, w, 128)
     with pytest.raises(ops.OtterHipError):
         ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), w, 128)   # CPU tensor: no fallback
+    with pytest.raises(TypeError):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.float16, device=dev), torch.zeros(128, 64, dtype=torch.bfloat16, device=dev), 128)
 
 
 @pytest.mark.parametrize("rows,width", [(37, 1024), (1, 768), (1000, 768), (9, 128), (5, 4096), (3, 64)])
-@pytest.mark.parametrize("out_f32", [False, True])
-def test_layernorm(dev, rows, width, out_f32):
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+def test_layernorm(dev, rows, width, dtype):
     from otter_amd import ops
     x = (_randn(8, rows, width) * 3 + 1).to(dev)
     g = (_randn(9, width) * 0.2 + 1).to(dev)
     b = _randn(10, width).to(dev)
-    y = ops.layernorm(x, g, b, out_f32=out_f32)
+    y = ops.layernorm(x, g, b, out_dtype=DTYPES[dtype])
     ref = torch.nn.functional.layer_norm(x, (width,), g, b, 1e-5)
-    tol = dict(rtol=1e-5, atol=1e-5) if out_f32 else dict(rtol=8e-3, atol=8e-3)   # bf16 rounding of the output
-    torch.testing.assert_close(y.float(), ref, **tol)
-    y2 = ops.layernorm(x, None, None, out_f32=True)
+    tol = {"f32": 1e-5, "bf16": 8e-3, "f16": 1e-3}[dtype]                 # rounding of the output type
+    torch.testing.assert_close(y.float(), ref, rtol=tol, atol=tol)
+    y2 = ops.layernorm(x, None, None, out_dtype=torch.float32)
     torch.testing.assert_close(y2, torch.nn.functional.layer_norm(x, (width,)), rtol=1e-5, atol=1e-5)
 
 
@@ -142,11 +157,12 @@ def test_im2col(dev, dtype):
         img = _randn(20, n, 3, res, res).to(dev)
         ref_img = img
     kpad = ops.round_up(3 * ps * ps, 64)
-    out = ops.im2col_patches(img, ps, kpad, R.CLIP_MEAN, R.CLIP_STD)
     ref = torch.nn.functional.unfold(ref_img, ps, stride=ps).transpose(1, 2).reshape(-1, 3 * ps * ps)
-    assert torch.all(out[:, 3 * ps * ps:] == 0)
-    # bit-exact after rounding the fp32 normalised pixel to bf16
-    assert torch.equal(out[:, :3 * ps * ps], ref.bfloat16())
+    for dt in (torch.bfloat16, torch.float16):
+        out = ops.im2col_patches(img, ps, kpad, R.CLIP_MEAN, R.CLIP_STD, dt)
+        assert torch.all(out[:, 3 * ps * ps:] == 0)
+        # bit-exact after rounding the fp32 normalised pixel to the 16-bit type
+        assert torch.equal(out[:, :3 * ps * ps], ref.to(dt))
 
 
 def _sdpa_ref(qkv, n_seq, L, heads, hd, causal):
@@ -158,14 +174,17 @@ def _sdpa_ref(qkv, n_seq, L, heads, hd, causal):
 
 
 @pytest.mark.parametrize("n_seq,L,heads,causal", [(3, 257, 16, False), (2, 15, 12, True), (2, 77, 12, True), (5, 17, 2, False),
-                                                  (1, 1, 1, True), (2, 65, 2, False), (1, 288, 1, False)])
-def test_attn_d64(dev, n_seq, L, heads, causal):
+                                                  (1, 1, 1, True), (2, 65, 2, False), (1, 288, 1, False), (2, 16, 3, True),
+                                                  (2, 40, 2, True), (1, 197, 12, False)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_attn_d64(dev, n_seq, L, heads, causal, dtype):
     from otter_amd import ops
-    qkv = _randn(21, n_seq * L, 3 * heads * 64).to(dev).bfloat16()
+    qkv = _randn(21, n_seq * L, 3 * heads * 64).to(dev).to(DTYPES[dtype])
     out = ops.attn_d64(qkv, n_seq, L, heads, causal)
     ref = _sdpa_ref(qkv, n_seq, L, heads, 64, causal)
-    # P is rounded to bf16 before P.V and the output is bf16: ~2^-8 relative on O(1) values
-    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=1.5e-2)
+    # P is rounded to the 16-bit type before P.V and so is the output: ~2^-8 (bf16) / 2^-11 (fp16) relative on O(1) values
+    tol = dict(rtol=2e-2, atol=1.5e-2) if dtype == "bf16" else dict(rtol=3e-3, atol=2e-3)
+    torch.testing.assert_close(out.float(), ref, **tol)
 
 
 def test_attn_d64_peaked_softmax(dev):
@@ -191,29 +210,32 @@ def test_attn_policy(dev, b, s, nq, pos0, heads, hd):
     q, k, v = cache.view(b, s, 3, heads, hd).permute(2, 0, 3, 1, 4)
     sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + torch.full((s, s), float("-inf"), device=dev).triu(1)
     ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(b, s, dim)[:, pos0:pos0 + nq].reshape(b * nq, dim)
-    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)     # bf16 output rounding
+    assert out.dtype == torch.float32
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)             # fp32 throughout
 
 
 @pytest.mark.parametrize("n_obs,cams,P,D,K,t_rep", [(2, 2, 256, 768, 15, 1), (6, 2, 256, 768, 15, 3), (3, 1, 64, 128, 15, 1),
                                                     (2, 2, 16, 128, 1, 2), (1, 2, 256, 768, 16, 1)])
 @pytest.mark.parametrize("temperature", [0.07, 0.005, 150.0])
-def test_text_aware_pool(dev, n_obs, cams, P, D, K, t_rep, temperature):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_text_aware_pool(dev, n_obs, cams, P, D, K, t_rep, temperature, dtype):
     from otter_amd import ops
-    patches = (_randn(24, n_obs * cams, P, D) * 1.7).to(dev).bfloat16()
+    dt = DTYPES[dtype]
+    patches = (_randn(24, n_obs * cams, P, D) * 1.7).to(dev).to(dt)
     text = (_randn(25, n_obs // t_rep, K, D) * 0.3).to(dev)
     pos = torch.stack([R.sincos_position_embedding(P, D) * (1 + 0.1 * c) for c in range(cams)]).to(dev)
     temp = torch.full((cams,), temperature, device=dev)
-    pos_t = torch.stack([ops.pos_emb_transpose(pos[c]) for c in range(cams)])
+    pos_t = torch.stack([ops.pos_emb_transpose(pos[c], dt) for c in range(cams)])
     out = ops.text_aware_pool(patches, text, pos_t, temp, n_obs, cams, t_rep)
     pf = patches.float().view(n_obs, cams, P, D)
     pf = pf / pf.norm(dim=-1, keepdim=True)
     tf = (text / text.norm(dim=-1, keepdim=True)).repeat_interleave(t_rep, 0)
     for c in range(cams):
         ref = R.text_aware_visual_extraction(pf[:, c].cpu(), tf.cpu(), torch.tensor(temperature), pos[c].cpu()).to(dev)
-        # bf16 rounding of text tokens, softmax weights and pos_emb: ~2^-8 relative to |pos_emb| <= 1; the logit
-        # error from the bf16 text tokens is amplified by 1/temperature (200x at 0.005)
-        tol = 4e-2 if temperature < 0.01 else 1e-2
-        torch.testing.assert_close(out[c], ref, rtol=2e-2, atol=tol)
+        # 16-bit rounding of text tokens, softmax weights and pos_emb: ~2^-8 (bf16) / 2^-11 (fp16) relative to
+        # |pos_emb| <= 1.1; the logit error from the rounded text tokens is amplified by 1/temperature (200x at 0.005)
+        tol = (4e-2 if temperature < 0.01 else 1e-2) if dtype == "bf16" else (5e-3 if temperature < 0.01 else 1.5e-3)
+        torch.testing.assert_close(out[c], ref, rtol=tol, atol=tol)
 
 
 @pytest.mark.parametrize("case_name", ["vision_nomask", "text_mask", "small"])
@@ -229,8 +251,8 @@ def test_readout_pool(dev, case_name):
     pw = PoolingWeights({k: v.to(dev) for k, v in sd.items()}, "", case["heads"])
     out = torch.zeros(case["B"], case["D_out"] + 8, device=dev)
     pw.forward(x.to(dev).reshape(-1, case["D_in"]), None if mask is None else mask.to(dev), out[:, 4:4 + case["D_out"]], case["B"], case["K"])
-    # k/v projections run on bf16 MFMA (inputs rounded to bf16), the rest is fp32
-    torch.testing.assert_close(out[:, 4:4 + case["D_out"]].cpu(), ref, rtol=2e-2, atol=2e-2)
+    # fp32 MFMA k/v projections + fp32 readout kernel
+    torch.testing.assert_close(out[:, 4:4 + case["D_out"]].cpu(), ref, rtol=1e-4, atol=2e-5)
     assert torch.all(out[:, :4] == 0) and torch.all(out[:, 4 + case["D_out"]:] == 0)
 
 
@@ -244,14 +266,17 @@ def test_small_ops(dev):
     b = _randn(29, 256).to(dev)
     y = ops.linear_f32(h, w.t().contiguous(), b, ops.ACT_RELU)
     torch.testing.assert_close(y, torch.relu(h @ w.t() + b), rtol=1e-5, atol=1e-5)
-    # cast with padding and repetition
-    c = ops.cast_bf16(x[:5, :700].contiguous(), cols_pad=704, rep=3)
-    assert c.shape == (15, 704) and torch.all(c[:, 700:] == 0)
-    assert torch.equal(c[:, :700], x[:5, :700].bfloat16().repeat_interleave(3, 0))
+    # row conversion with padding and repetition
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        c = ops.convert_rows(x[:5, :700].contiguous(), dt, cols_pad=704, rep=3)
+        assert c.shape == (15, 704) and c.dtype == dt and torch.all(c[:, 700:] == 0)
+        assert torch.equal(c[:, :700], x[:5, :700].to(dt).repeat_interleave(3, 0))
     pick = torch.tensor([0, 3, 1], dtype=torch.int32, device=dev)
     src = _randn(30, 12, 64).to(dev)
-    sel = ops.cast_bf16(src, pick=pick, group=4)
-    assert torch.equal(sel, src.view(3, 4, 64)[torch.arange(3), pick.long().cpu()].bfloat16())
+    sel = ops.convert_rows(src, pick=pick, group=4)
+    assert torch.equal(sel, src.view(3, 4, 64)[torch.arange(3), pick.long().cpu()])
+    sel = ops.convert_rows(src, pick=pick + 1, group=4, pick_bias=-1)
+    assert torch.equal(sel, src.view(3, 4, 64)[torch.arange(3), pick.long().cpu()])
     dst = torch.zeros(10, 40, device=dev)
     ops.repeat_rows(src[:5, :32], dst[:, 4:36], 2)
     assert torch.equal(dst[:, 4:36], src[:5, :32].repeat_interleave(2, 0)) and torch.all(dst[:, :4] == 0)

@@ -34,6 +34,7 @@ extern "C" {
 #define OTTER_EPI_ACT_MASK 3
 #define OTTER_EPI_OUT_F32 4       /* write fp32 instead of the 16-bit operand type (always on for fp32 operands) */
 #define OTTER_EPI_RESIDUAL 8      /* out = acc + bias + residual (fp32), requires OUT_F32 and ACT_NONE */
+#define OTTER_EPI_TILE_128 16     /* tuning knob: always use the 128x128-tile kernel (default picks 256x256 for big shapes) */
 
 int otter_hip_abi_version(void);
 const char* otter_last_error(void);

@@ -19,6 +19,7 @@ DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
 OUT_F32 = 4
 RESIDUAL = 8
+TILE_128 = 16
 
 
 class OtterHipError(RuntimeError):

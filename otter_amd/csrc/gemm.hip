@@ -20,6 +20,11 @@
 #include "common.hpp"
 #include "otter_hip.h"
 
+// 256x256-tile kernel for the big 16-bit shapes (gemm256.hip)
+bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K);
+int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -228,8 +233,21 @@ extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int
         OTTER_REQUIRE(out_f32 && act == OTTER_EPI_ACT_NONE, OTTER_ERR_UNSUPPORTED_SHAPE,
                       "otter_gemm: residual epilogue is fp32-out, no activation");
     }
-    GemmArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, tiles_m, tiles_n};
     hipStream_t s = (hipStream_t)stream;
+    if (!(epilogue & OTTER_EPI_TILE_128) && otter_gemm256_eligible(dtype, lda, n_pad, M, N, K)) {
+        // Rows are independent: whole 256-row tiles go to the 256x256 kernel, the remaining (< 256) rows to the
+        // 128x128 kernel, so the big kernel's last round never runs mostly-empty tiles.
+        const int m_main = (M / 256) * 256;
+        int rc = otter_gemm256_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, m_main, N, K, act, out_f32, res, s);
+        if (rc != OTTER_OK || m_main == M) return rc;
+        const long ec = (out_f32 ? 4 : es);
+        A = (const char*)A + (long)m_main * lda * es;
+        C = (char*)C + (long)m_main * ldc * ec;
+        if (res) residual += (long)m_main * ldr;
+        M -= m_main;
+    }
+    const int tm = (M + BM - 1) / BM;
+    GemmArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, tm, tiles_n};
     if (dtype == DT_BF16) return dispatch<__bf16>(a, act, out_f32, res, s);
     if (dtype == DT_F16) return dispatch<_Float16>(a, act, out_f32, res, s);
     return dispatch<float>(a, act, true, res, s);

@@ -1,0 +1,295 @@
+// 256x256-tile MFMA GEMM for the large CLIP-tower shapes (bf16 / fp16 operands, fp32 accumulation).
+//
+//   C[M,N] = epi(A[M,K] * W[N,K]^T + bias [+ residual])     same contract as the 128x128 kernel in gemm.hip
+//
+// One workgroup = 8 waves (2 along M x 4 along N) = one 256x256 output tile, one workgroup per CU; each wave
+// owns 128(M) x 64(N) = 8x4 accumulator tiles of 16x16 (128 accumulator registers).  A K-step is 64 elements
+// (128 bytes per row).
+//
+// Data movement.  Each operand tile of a K-step is cut into two 16 KiB "half-tiles" (128 rows x 128 bytes):
+//   A_h0 = tile rows {0..63, 128..191}   A_h1 = tile rows {64..127, 192..255}
+//   B_h0 = tile cols {64c + 0..31}       B_h1 = tile cols {64c + 32..63}        (c = 0..3)
+// so that every wave's work splits into four quadrants q0=(A_h0,B_h0) q1=(A_h0,B_h1) q2=(A_h1,B_h1) q3=(A_h1,B_h0),
+// 16 MFMAs each, executed in that (snake) order: one phase per quadrant, each phase = a load segment (fragment
+// reads of the operand half that changed + one LDS-DMA half-tile issue) and an MFMA segment, separated by barriers.
+// LDS holds two K-steps x four half-tile slots (128 KiB).  Half-tiles arrive by LDS-DMA (global_load_lds_dwordx4,
+// two instructions per thread per half-tile) and a slot is refilled as soon as its last reader phase is over:
+//   phase (t,0): A_h1(t+1)   (t,1): B_h0(t+1)   (t,2): A_h0(t+2)   (t,3): B_h1(t+2)
+// Every load therefore has 3..6 phases (>= 768 MFMA cycles) to land, and only ONE counted wait per K-step is
+// needed: s_waitcnt vmcnt(4) at the end of phase 3 leaves the two youngest half-tiles in flight and guarantees
+// that all of K-step t+1 has landed (the barrier that follows publishes it to the other waves).  The loop never
+// drains the memory queue; raw s_barrier is used because __syncthreads() would add vmcnt(0).
+//
+// Write-after-read safety: a slot's refill is issued at least one barrier after the last phase that reads it
+// (A_h0: read in phases 0,1 -> refilled in phase 2; B_h1: 1,2 -> 3; A_h1: 2,3 -> next phase 0; B_h0: 0,3 -> next 1).
+//
+// LDS images are lane-linear (LDS-DMA requirement) with the 16-byte chunk index XOR-swizzled on the source
+// address and on the ds_read_b128 address, as in gemm.hip.
+#include "common.hpp"
+#include "otter_hip.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256;
+constexpr int HALF_BYTES = 128 * 128;             // one half-tile
+constexpr int LDS_BYTES = 2 * 4 * HALF_BYTES;     // 128 KiB
+constexpr int GROUP_M256 = 4;
+
+struct Gemm256Args {
+    const char* A; long lda;
+    const char* W;
+    const float* bias;
+    const float* residual; long ldr;
+    void* C; long ldc;
+    int M, N, K, tiles_m, tiles_n;
+};
+
+enum { SLOT_A0 = 0, SLOT_B0 = 1, SLOT_B1 = 2, SLOT_A1 = 3 };
+enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU = 2, ACT_RELU = 3 };
+
+template <int ACT> __device__ __forceinline__ float act256(float v) {
+    if (ACT == ACT_QUICKGELU) return quick_gelu(v);
+    if (ACT == ACT_GELU) return gelu_erf(v);
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <typename T, int ACT, bool OUT_F32, bool RES>
+__global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Half16<T>::v8 frag_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int pid = xcd_remap(blockIdx.x, nwg);
+    const int width = GROUP_M256 * p.tiles_n;
+    const int first_m = (pid / width) * GROUP_M256;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M256);
+    const int tm = first_m + (pid % width) % gsz;
+    const int tn = (pid % width) / gsz;
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    // ---- LDS-DMA source offsets (bytes from A / W), two instructions per half-tile per thread ----
+    unsigned a_off[2][2], w_off[2][2];      // [half][instruction]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = (wave * 2 + i) * 8 + (lane >> 3);            // local row inside the half-tile image
+        const int c = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int trow = (lr < 64 ? lr : lr + 64) + x * 64;      // A: tile row
+            const int tcol = (lr >> 5) * 64 + x * 32 + (lr & 31);    // W: tile column
+            a_off[x][i] = (unsigned)min(m0 + trow, p.M - 1) * (unsigned)(p.lda * 2) + c * 16;
+            w_off[x][i] = (unsigned)(n0 + tcol) * (unsigned)(p.K * 2) + c * 16;
+        }
+    }
+    auto issue = [&](int buf, int slot, int kt) {
+        char* dst = smem + (buf * 4 + slot) * HALF_BYTES + wave * 2048;
+        const unsigned kb = (unsigned)kt * 128u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* src;
+            if (slot == SLOT_A0) src = p.A + (a_off[0][i] + kb);
+            else if (slot == SLOT_A1) src = p.A + (a_off[1][i] + kb);
+            else if (slot == SLOT_B0) src = p.W + (w_off[0][i] + kb);
+            else src = p.W + (w_off[1][i] + kb);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets inside a half-tile image ----
+    const int swz = (li >> 1) & 7;
+    int koff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) koff[ks] = li * 128 + (((ks * 4 + g) ^ swz) << 4);
+    const int a_row0 = wr * 64 * 128;          // this wave's 64 rows inside an A half-tile
+    const int b_row0 = wc * 32 * 128;          // this wave's 32 rows inside a B half-tile
+
+    f32x4 acc[2][2][4][2];                      // [A half s][B half x][m-tile][n-tile]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[s][x][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = p.K / 64;
+
+    // ---- prologue: K-step 0 completely, plus the two half-tiles of K-step 1 that phases (-1,2) and (-1,3) would issue
+    issue(0, SLOT_A0, 0);
+    issue(0, SLOT_B1, 0);
+    issue(0, SLOT_A1, 0);
+    issue(0, SLOT_B0, 0);
+    if (nkt > 1) {
+        issue(1, SLOT_A0, 1);
+        issue(1, SLOT_B1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    wg_barrier();
+
+    frag_t af[4][2], bf[2][2];
+    auto load_a = [&](int buf, int slot) {
+        const char* base = smem + (buf * 4 + slot) * HALF_BYTES + a_row0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const frag_t*)(base + mt * 2048 + koff[ks]);
+    };
+    auto load_b = [&](int buf, int slot) {
+        const char* base = smem + (buf * 4 + slot) * HALF_BYTES + b_row0;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bf[nt][ks] = *(const frag_t*)(base + nt * 2048 + koff[ks]);
+    };
+#define OTTER_QUADRANT(S, X)                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                   \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                               \
+                acc[S][X][mt][nt] = Half16<T>::mfma32(bf[nt][ks], af[mt][ks], acc[S][X][mt][nt]);
+
+    // Two wave groups (waves 0-3 / 4-7; each SIMD hosts one wave of each) run the same program one barrier apart:
+    // while one group is in a load segment (LDS fragment reads + LDS-DMA issue) the other is in its MFMA segment,
+    // so the matrix pipe of every SIMD always has a wave feeding it.  Segments are separated by workgroup
+    // barriers; group 1 starts one barrier late and group 0 ends with one extra barrier.  The counted wait that
+    // retires K-step t+1 sits at the end of the same global segment for both groups (end of the MFMA segment of
+    // phase 3 for group 0, end of the load segment of phase 3 for group 1), one barrier before its first reader.
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+#define OTTER_SEG_END()                                     \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    wg_barrier();                                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define OTTER_MFMA_SEG(S, X)                                \
+    __builtin_amdgcn_s_setprio(1);                          \
+    OTTER_QUADRANT(S, X)                                    \
+    __builtin_amdgcn_s_setprio(0);
+#define OTTER_RETIRE_NEXT()                                                       \
+    if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (late) { OTTER_SEG_END() }
+    for (int t = 0; t < nkt; ++t) {
+        const int buf = t & 1;
+        // phase 0: q0 = (A_h0, B_h0)
+        load_a(buf, SLOT_A0);
+        load_b(buf, SLOT_B0);
+        if (t + 1 < nkt) issue(buf ^ 1, SLOT_A1, t + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        OTTER_SEG_END()
+        OTTER_MFMA_SEG(0, 0)
+        OTTER_SEG_END()
+        // phase 1: q1 = (A_h0, B_h1)
+        load_b(buf, SLOT_B1);
+        if (t + 1 < nkt) issue(buf ^ 1, SLOT_B0, t + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        OTTER_SEG_END()
+        OTTER_MFMA_SEG(0, 1)
+        OTTER_SEG_END()
+        // phase 2: q2 = (A_h1, B_h1)
+        load_a(buf, SLOT_A1);
+        if (t + 2 < nkt) issue(buf, SLOT_A0, t + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        OTTER_SEG_END()
+        OTTER_MFMA_SEG(1, 1)
+        OTTER_SEG_END()
+        // phase 3: q3 = (A_h1, B_h0)
+        load_b(buf, SLOT_B0);
+        if (t + 2 < nkt) issue(buf, SLOT_B1, t + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (late) { OTTER_RETIRE_NEXT() }
+        OTTER_SEG_END()
+        OTTER_MFMA_SEG(1, 0)
+        if (!late) { OTTER_RETIRE_NEXT() }
+        OTTER_SEG_END()
+    }
+    if (!late) { OTTER_SEG_END() }
+#undef OTTER_SEG_END
+#undef OTTER_MFMA_SEG
+#undef OTTER_RETIRE_NEXT
+#undef OTTER_QUADRANT
+
+    // ---- epilogue: accumulator tile = D[row n][col m]; lane holds m = li, n = 4g + 0..3 ----
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + wc * 64 + x * 32 + nt * 16 + g * 4;
+            if (n >= p.N) continue;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int m = m0 + wr * 128 + s * 64 + mt * 16 + li;
+                    if (m >= p.M) continue;
+                    f32x4 v = acc[s][x][mt][nt] + b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act256<ACT>(v[e]);
+                    if (RES) v += *(const f32x4*)(p.residual + (long)m * p.ldr + n);
+                    if constexpr (OUT_F32) {
+                        *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
+                    } else {
+                        typename Half16<T>::v4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = Half16<T>::from(v[e]);
+                        *(typename Half16<T>::v4*)((T*)p.C + (long)m * p.ldc + n) = o;
+                    }
+                }
+        }
+}
+
+template <typename T, int ACT, bool OUT_F32, bool RES>
+int launch256(const Gemm256Args& a, hipStream_t s) {
+    auto kern = gemm_256x256<T, ACT, OUT_F32, RES>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) {
+            otter_set_error("otter_gemm (256x256): cannot reserve %d bytes of LDS: %s", LDS_BYTES, hipGetErrorString(e));
+            return OTTER_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), LDS_BYTES, s, a);
+    OTTER_CHECK_LAUNCH("otter_gemm (256x256)");
+    return OTTER_OK;
+}
+
+template <typename T>
+int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, hipStream_t s) {
+    if (res) return launch256<T, ACT_NONE, true, true>(a, s);
+    switch (act) {
+        case OTTER_EPI_ACT_NONE: return out_f32 ? launch256<T, ACT_NONE, true, false>(a, s) : launch256<T, ACT_NONE, false, false>(a, s);
+        case OTTER_EPI_ACT_QUICKGELU: return out_f32 ? launch256<T, ACT_QUICKGELU, true, false>(a, s) : launch256<T, ACT_QUICKGELU, false, false>(a, s);
+        case OTTER_EPI_ACT_GELU: return out_f32 ? launch256<T, ACT_GELU, true, false>(a, s) : launch256<T, ACT_GELU, false, false>(a, s);
+        case OTTER_EPI_ACT_RELU: return out_f32 ? launch256<T, ACT_RELU, true, false>(a, s) : launch256<T, ACT_RELU, false, false>(a, s);
+    }
+    otter_set_error("otter_gemm: unknown activation %d", act);
+    return OTTER_ERR_INVALID_ARGUMENT;
+}
+
+}  // namespace
+
+// Shapes the 256x256 kernel accepts (checked by the caller in gemm.hip, which owns the argument validation).
+bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K) {
+    if (dtype != DT_BF16 && dtype != DT_F16) return false;
+    if (M < 1024 || N < 256 || K % 64 != 0) return false;                       // small problems: 128x128 tiles fill the chip better
+    if (n_pad < ((N + TN - 1) / TN) * TN) return false;                          // weight rows must cover whole 256-column tiles
+    if ((long)M * lda * 2 >= (1L << 32) || (long)n_pad * K * 2 >= (1L << 32)) return false;   // 32-bit source offsets
+    return true;
+}
+
+int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s) {
+    Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, (N + TN - 1) / TN};
+    return dtype == DT_BF16 ? dispatch256<__bf16>(a, act, out_f32, res, s) : dispatch256<_Float16>(a, act, out_f32, res, s);
+}

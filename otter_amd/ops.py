@@ -12,11 +12,11 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, DT_BF16, DT_F16, DT_F32, OUT_F32, RESIDUAL,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, DT_BF16, DT_F16, DT_F32, OUT_F32, RESIDUAL, TILE_128,  # noqa: F401
                    OtterHipError, ReadoutBlock)
 
 Tensor = torch.Tensor
-GEMM_N_ALIGN = 128
+GEMM_N_ALIGN = 256          # weight rows are padded so that both the 128x128 and the 256x256 tile kernels can read whole tiles
 GEMM_K_BYTES = 128          # a K-step of the GEMM is 128 bytes per row: 64 halves or 32 floats
 
 DT = {torch.bfloat16: DT_BF16, torch.float16: DT_F16, torch.float32: DT_F32}
@@ -78,7 +78,8 @@ def pack_weight(w: Tensor, dtype=torch.bfloat16, device=None) -> Tensor:
 # ----------------------------------------------------------------------------------------- kernels
 
 def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
-         out_f32: bool = False, residual: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+         out_f32: bool = False, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
+         force_tile_128: bool = False) -> Tensor:
     """out[M, n] = epilogue(a[M, K] @ w[n, K]^T + bias); operands bf16 / fp16 / fp32 (``w_packed`` from
     :func:`pack_weight` with the same dtype); output the operand type, or fp32 (``out_f32``, residual, fp32 operands)."""
     dt = _dt(a.dtype, "gemm.a")
@@ -94,7 +95,7 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         if bias.numel() < n:
             raise ValueError("gemm: bias shorter than N")
     f32_out = out_f32 or residual is not None or a.dtype == torch.float32
-    epi = act | (OUT_F32 if f32_out else 0) | (RESIDUAL if residual is not None else 0)
+    epi = act | (OUT_F32 if f32_out else 0) | (RESIDUAL if residual is not None else 0) | (TILE_128 if force_tile_128 else 0)
     odt = torch.float32 if f32_out else a.dtype
     if out is None:
         out = torch.empty(m, n, dtype=odt, device=a.device)

@@ -45,7 +45,7 @@ DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
 @pytest.mark.parametrize("m,n,k", [(300, 256, 128), (1000, 3072, 1024), (129, 120, 1536), (5, 768, 704), (2056, 1024, 4096),
-                                   (1, 128, 64), (64, 2304, 768)])
+                                   (1, 128, 64), (64, 2304, 768), (1500, 1000, 512), (1024, 256, 64)])
 @pytest.mark.parametrize("act", ["none", "quickgelu", "gelu", "relu"])
 @pytest.mark.parametrize("out_f32", [False, True])
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
@@ -78,9 +78,10 @@ def test_gemm(dev, m, n, k, act, out_f32, dtype):
     torch.testing.assert_close(out.float(), ref, **tol)
 
 
-def test_gemm_residual_strided_inplace(dev):
+@pytest.mark.parametrize("m", [777, 1300])          # 128-row tiles only / 256-row tiles plus a 128-row-tile remainder
+def test_gemm_residual_strided_inplace(dev, m):
     from otter_amd import ops
-    m, n, k = 777, 1024, 1024
+    n, k = 1024, 1024
     big_a = torch.zeros(m, k + 64, dtype=torch.bfloat16, device=dev)
     a = big_a[:, :k]
     a.copy_(_randn(4, m, k))
@@ -100,13 +101,15 @@ def test_gemm_residual_strided_inplace(dev):
 def test_gemm_rejects_bad_arguments(dev):
     from otter_amd import ops
     a = torch.zeros(4, 100, dtype=torch.bfloat16, device=dev)     # K not a multiple of 64
-    w = torch.zeros(128, 100, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(256, 100, dtype=torch.bfloat16, device=dev)
     with pytest.raises(ops.OtterHipError):
         ops.gemm(a, w, 128)
     with pytest.raises(ops.OtterHipError):
-        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), w, 128)   # CPU tensor: no fallback
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(256, 64, dtype=torch.bfloat16, device=dev), 128)   # CPU tensor: no fallback
     with pytest.raises(TypeError):
-        ops.gemm(torch.zeros(4, 64, dtype=torch.float16, device=dev), torch.zeros(128, 64, dtype=torch.bfloat16, device=dev), 128)
+        ops.gemm(torch.zeros(4, 64, dtype=torch.float16, device=dev), torch.zeros(256, 64, dtype=torch.bfloat16, device=dev), 128)
+    with pytest.raises(ValueError):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16, device=dev), torch.zeros(128, 64, dtype=torch.bfloat16, device=dev), 128)   # unpadded weight
 
 
 @pytest.mark.parametrize("rows,width", [(37, 1024), (1, 768), (1000, 768), (9, 128), (5, 4096), (3, 64)])

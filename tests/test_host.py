@@ -1,0 +1,200 @@
+"""CPU tests: host-side logic of the product (tokenizer, config, pose/action helpers, checkpoint contract) and the
+C-ABI library's exported symbols.  No GPU compute is called here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "otter_hip.h")).read()
+    declared = set(re.findall(r"\b(otter_[a-z0-9_]+)\s*\(", header))
+    declared.discard("otter_readout_block")
+    assert len(declared) >= 15
+    from otter_amd import _lib
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libotter_hip.so does not export {name}"
+    assert set(_lib.exported_names()) == declared, (set(_lib.exported_names()) ^ declared)
+    assert lib.otter_hip_abi_version() == _lib.ABI_VERSION
+    m = re.search(r"#define OTTER_HIP_ABI_VERSION (\d+)", header)
+    assert int(m.group(1)) == _lib.ABI_VERSION
+
+
+def test_abi_argument_validation_without_gpu():
+    """Argument checks run before any launch, so they can be exercised on a machine without a GPU."""
+    from otter_amd import _lib
+    lib = _lib.load()
+    rc = lib.otter_gemm(0, None, 0, None, 0, None, None, 0, None, 0, 1, 1, 1, 0, None)
+    assert rc != 0 and b"null operand" in lib.otter_last_error()
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.otter_gemm(0, p, 100, p, 128, None, None, 0, p, 128, 4, 128, 100, 0, None)    # K % 64 != 0
+    assert rc == 2 and b"multiple of 64" in lib.otter_last_error()
+    rc = lib.otter_gemm(7, p, 64, p, 128, None, None, 0, p, 128, 4, 128, 64, 0, None)      # unknown dtype
+    assert rc == 1
+    rc = lib.otter_attn_fwd_d64(0, p, 192, p, 64, 1, 300, 1, 0, None)                      # L too long
+    assert rc == 2 and b"288" in lib.otter_last_error()
+
+
+def test_ops_refuse_cpu_tensors():
+    from otter_amd import ops
+    with pytest.raises(ops.OtterHipError):
+        ops.layernorm(torch.zeros(2, 64), None, None)
+    from otter_amd.config import ModelConfig, SharedConfig
+    from otter_amd.otter import OTTER
+    m = OTTER(ModelConfig(clip_model="tiny-test"), SharedConfig(image_size=112))
+    with pytest.raises(ops.OtterHipError):
+        m.forward_inference(torch.zeros(2, 3, 112, 112), torch.zeros(77, dtype=torch.int32), torch.zeros(10))
+
+
+# ---------------------------------------------------------------- checkpoint contract
+def test_state_dict_layout_and_counts():
+    from otter_amd.config import ModelConfig, SharedConfig
+    from otter_amd.params import otter_specs
+    specs = otter_specs(ModelConfig(), SharedConfig())
+    numel = lambda s: int(np.prod(s.shape)) if s.shape else 1     # noqa: E731
+    clip = sum(numel(s) for s in specs if s.key.startswith("clip_model."))
+    trainable = sum(numel(s) for s in specs if s.kind == "param")
+    policy = sum(numel(s) for s in specs if s.key.startswith("policy."))
+    assert clip == 427_616_513            # OpenAI ViT-L/14
+    assert trainable == 31_055_290        # gradient all-reduce message of the training step (x4 bytes = 124.2 MB)
+    assert policy == 28_372_992
+    keys = [s.key for s in specs]
+    assert len(keys) == len(set(keys))
+    for k in ("clip_model.visual.transformer.resblocks.23.attn.in_proj_weight", "text_pooling.blocks.1.attention.k_proj_weight",
+              "visual_extraction.1.pos_emb", "vision_poolings.0.query", "proprio_encoder.mlp.4.bias", "input_projection.weight",
+              "pe.pe", "policy.layers.7.attention.value.bias", "action_head.mlp.2.weight"):
+        assert k in keys
+
+
+def test_model_object_mirrors_reference_attributes(tmp_path):
+    from otter_amd.config import ExperimentConfig, ModelConfig, SharedConfig, dump_run_yaml, load_run_yaml
+    from otter_amd.otter import OTTER
+    from otter_amd.otter_interface import load_state_dict_flexible
+    mc, sc = GI.e2e_configs(GI.E2E_CASES[0])
+    m = OTTER(mc, sc)
+    for attr in ("camera_keys", "action_horizon", "action_dim", "seq_length", "pool_true_text", "sot_token", "eot_token",
+                 "first_k_tokens", "proprio_input_dim", "cached_transformer_input", "cache_size", "image_size"):
+        assert hasattr(m, attr)
+    assert m.camera_keys == ["image_primary", "image_wrist"] and m.sot_token == 49406 and m.eot_token == 49407
+    assert m.cached_transformer_input is None and m.cache_size == 0
+    assert all(not p.requires_grad for n, p in m.named_parameters() if n.startswith("clip_model."))
+    assert m.visual_extraction[0].temperature.requires_grad and float(m.visual_extraction[0].temperature.detach()) == pytest.approx(0.07)
+    assert "visual_extraction.0.pos_emb" in dict(m.named_buffers())
+    # DDP-style checkpoints load, wrong keys are rejected (strict)
+    sd = {"module." + k: v for k, v in m.state_dict().items()}
+    load_state_dict_flexible(OTTER(mc, sc), sd)
+    bad = dict(m.state_dict())
+    bad.pop("pe.pe")
+    with pytest.raises(RuntimeError):
+        OTTER(mc, sc).load_state_dict(bad)
+    # run.yaml round trip, including the reference's python-object tags and an unknown data-layer reference
+    cfg = ExperimentConfig(model_cfg=mc, shared_cfg=sc)
+    path = tmp_path / "run.yaml"
+    dump_run_yaml(cfg, path)
+    text = path.read_text()
+    assert "!!python/object:otter.util.args.ModelConfig" in text
+    path.write_text(text + "dataset_cfg: !!python/object:otter.util.args.DatasetConfig\n"
+                           "  restructure: !!python/name:otter.data.dataset.bridge_restructure ''\n"
+                           "  sample_weights: !!python/tuple [1.5, 2.5]\ntrain: true\n")
+    back = load_run_yaml(path)
+    assert back.model_cfg == mc and back.shared_cfg == sc
+    assert back.extras["train"] is True and back.extras["dataset_cfg"]["sample_weights"] == (1.5, 2.5)
+
+
+# ---------------------------------------------------------------- host helpers vs the reference's outputs
+def test_host_helpers_match_reference_fixtures(golden):
+    from PIL import Image
+    from otter_amd.action_utils import action_10d_to_7d, convert_abs_action
+    from otter_amd.otter import create_text_mask
+    from otter_amd.vision_tf import clip_transform_host, crop2square
+    g = golden("host")
+    toks = GI.text_tokens()
+    assert np.array_equal(create_text_mask(toks, 49406, 49407, 15).numpy(), g["mask_2d"])
+    assert np.array_equal(create_text_mask(toks[1], 49406, 49407, 15).numpy(), g["mask_1d"])
+    assert np.array_equal(create_text_mask(toks, 49406, 49407, 5).numpy(), g["mask_k5"])
+    u8, f_big, f_unit = GI.transform_inputs()
+    np.testing.assert_allclose(clip_transform_host(u8).numpy(), g["clip_transform_u8"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(clip_transform_host(f_big).numpy(), g["clip_transform_float_gt1"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(clip_transform_host(f_unit).numpy(), g["clip_transform_float_unit"], rtol=1e-6, atol=1e-6)
+    for i, (act, prop) in enumerate(GI.abs_action_inputs()):
+        np.testing.assert_allclose(convert_abs_action(act.copy(), prop.copy()), g[f"abs_action_{i}"], rtol=1e-12, atol=1e-12)
+    a10 = GI.action10_inputs()
+    np.testing.assert_allclose(np.stack([action_10d_to_7d(a.copy()) for a in a10]), g["action_10d_to_7d"], rtol=1e-12, atol=1e-12)
+    sizes = [crop2square(Image.new("RGB", wh)).size for wh in GI.CROP_SIZES]
+    assert np.array_equal(np.asarray(sizes), g["crop2square_sizes"])
+
+
+def test_proprio_preprocessing_and_action_decode():
+    """otter_interface.py:60-84 and :113-133 on the host (no model needed)."""
+    from scipy.spatial.transform import Rotation
+    from otter_amd.otter_interface import OtterInference
+    obj = OtterInference.__new__(OtterInference)
+    pose = np.array([0.3, -0.2, 0.5, 0.1, -0.4, 1.2])
+    t = obj._proprocess_proprio(pose, np.array([1.7]))
+    R = Rotation.from_euler("XYZ", pose[3:]).as_matrix()
+    expect = np.concatenate([pose[:3], R[0], R[1], [1.0]])
+    np.testing.assert_allclose(obj.current_proprio, expect, rtol=0, atol=1e-15)
+    assert t.dtype == torch.float32 and t.shape == (10,)
+    # a zero-translation, identity-rotation delta chunk decodes to the current pose
+    chunk = np.tile(np.concatenate([np.zeros(3), [1, 0, 0, 0, 1, 0], [0.5]]), (12, 1))
+    out = obj._decode_actions(torch.from_numpy(chunk))
+    np.testing.assert_allclose(out[:, :9], np.tile(expect[:9], (12, 1)), atol=1e-12)
+    np.testing.assert_allclose(out[:, 9], 0.5)
+
+
+# ---------------------------------------------------------------- tokenizer
+def _toy_tokenizer():
+    from otter_amd.tokenizer import SimpleTokenizer
+    merges = [("t", "h"), ("th", "e</w>"), ("c", "u"), ("b", "e</w>"), ("cu", "be</w>"), ("p", "i"), ("pi", "c"), ("pic", "k</w>"),
+              ("u", "p</w>"), ("r", "e"), ("re", "d</w>")]
+    return SimpleTokenizer(merges=merges)
+
+
+def test_bpe_on_synthetic_merges():
+    from otter_amd.tokenizer import tokenize
+    tk = _toy_tokenizer()
+    sot, eot = tk.encoder["<|startoftext|>"], tk.encoder["<|endoftext|>"]
+    assert (sot, eot) == (512 + 11, 512 + 12)        # vocabulary order: 256 bytes, 256 byte</w>, merges, specials
+    ids = tk.encode("Pick  up the\nRED cube!")
+    words = [tk.decoder[i] for i in ids]
+    assert words == ["pick</w>", "up</w>", "the</w>", "red</w>", "cube</w>", "!</w>"]
+    assert tk.decode(ids) == "pick up the red cube ! "
+    # single characters, digits split one by one, apostrophe suffixes, html entities, unicode bytes
+    assert [tk.decoder[i] for i in tk.encode("a 42 it's &amp;")] == ["a</w>", "4</w>", "2</w>", "i", "t</w>", "'", "s</w>", "&</w>"]   # "'s" is one regex piece; no merge joins it here
+    assert tk.decode(tk.encode("café")) == "café "
+    out = tokenize(["pick up the cube", ""], context_length=10, tokenizer=tk)
+    assert out.dtype == torch.int32 and out.shape == (2, 10)
+    assert out[0].tolist() == [sot] + tk.encode("pick up the cube") + [eot] + [0] * 4
+    assert out[1].tolist() == [sot, eot] + [0] * 8
+    with pytest.raises(RuntimeError):
+        tokenize(["the " * 20], context_length=10, tokenizer=tk)
+    cut = tokenize(["the " * 20], context_length=10, truncate=True, tokenizer=tk)
+    assert cut[0, 0] == sot and cut[0, -1] == eot
+
+
+def test_real_vocabulary_known_answer_if_available():
+    """Known answer from the public CLIP documentation; runs only where the merges file is supplied."""
+    from otter_amd.tokenizer import SimpleTokenizer, tokenize
+    path = os.environ.get("OTTER_CLIP_BPE")
+    if not path or not os.path.exists(path):
+        pytest.skip("set OTTER_CLIP_BPE to bpe_simple_vocab_16e6.txt.gz to run (file is not redistributed)")
+    tk = SimpleTokenizer(path)
+    assert tokenize(["a photo of a cat"], tokenizer=tk)[0, :7].tolist() == [49406, 320, 1125, 539, 320, 2368, 49407]
+
+
+def test_tokenizer_without_vocabulary_fails_loudly(monkeypatch):
+    from otter_amd import tokenizer
+    monkeypatch.delenv("OTTER_CLIP_BPE", raising=False)
+    monkeypatch.setattr(tokenizer, "_default", None)
+    with pytest.raises(FileNotFoundError):
+        tokenizer.tokenize(["pick up the cube"])

@@ -177,25 +177,12 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     work = Workload(device, seed=rank, clip_dtype=torch.float16 if args.clip_dtype == "f16" else torch.bfloat16)
+    from otter_amd.sharding import timed_region
     for _ in range(args.warmup):
         work.step()
     work.t = 0                                           # timed region starts at an episode boundary
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        work.step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # barrier + device sync on both sides of exactly `steps` steps; MAX over ranks
+    elapsed = timed_region(work.step, args.steps, world=world, sync=torch.cuda.synchronize, device=device)
 
     result = None
     if rank == 0:

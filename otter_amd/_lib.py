@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libotter_hip.so")
+LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
 ABI_VERSION = 2
 

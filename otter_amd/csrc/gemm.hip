@@ -21,7 +21,7 @@
 #include "otter_hip.h"
 
 // 256x256-tile kernel for the big 16-bit shapes (gemm256.hip)
-bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K);
+bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc);
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
                          void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
 
@@ -234,7 +234,7 @@ extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int
                       "otter_gemm: residual epilogue is fp32-out, no activation");
     }
     hipStream_t s = (hipStream_t)stream;
-    if (!(epilogue & OTTER_EPI_TILE_128) && otter_gemm256_eligible(dtype, lda, n_pad, M, N, K)) {
+    if (!(epilogue & OTTER_EPI_TILE_128) && otter_gemm256_eligible(dtype, lda, n_pad, M, N, K, C, ldc)) {
         // Rows are independent: whole 256-row tiles go to the 256x256 kernel, the remaining (< 256) rows to the
         // 128x128 kernel, so the big kernel's last round never runs mostly-empty tiles.
         const int m_main = (M / 256) * 256;

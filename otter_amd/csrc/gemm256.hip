@@ -2,7 +2,9 @@
 //
 //   C[M,N] = epi(A[M,K] * W[N,K]^T + bias [+ residual])     same contract as the 128x128 kernel in gemm.hip
 //
-// One workgroup = 8 waves (2 along M x 4 along N) = one 256x256 output tile, one workgroup per CU; each wave
+// One workgroup = 8 waves (2 along M x 4 along N) works on one 256x256 output tile at a time, one persistent
+// workgroup per CU looping over tiles (M must be a multiple of 256: the caller routes remainder rows to the
+// 128x128 kernel); each wave
 // owns 128(M) x 64(N) = 8x4 accumulator tiles of 16x16 (128 accumulator registers).  A K-step is 64 elements
 // (128 bytes per row).
 //
@@ -65,28 +67,34 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     const int g = lane >> 4, li = lane & 15;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int pid = xcd_remap(blockIdx.x, nwg);
-    const int width = GROUP_M256 * p.tiles_n;
-    const int first_m = (pid / width) * GROUP_M256;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M256);
-    const int tm = first_m + (pid % width) % gsz;
-    const int tn = (pid % width) / gsz;
-    const int m0 = tm * TM, n0 = tn * TN;
-
-    // ---- LDS-DMA source offsets (bytes from A / W), two instructions per half-tile per thread ----
-    unsigned a_off[2][2], w_off[2][2];      // [half][instruction]
+    const int nkt = p.K / 64;
+    int m0, n0;
+    unsigned a_off[2][2], w_off[2][2];      // LDS-DMA source offsets (bytes from A / W): [half][instruction]
+    // Tile `t` of the launch order -> (m0, n0) and the per-thread source offsets of its half-tiles.  Image row lr
+    // of a W half-tile holds the weight row the MFMA fragment order wants there: fragment row (nt, i) of a wave's
+    // 32 columns is column 8*(i>>2) + 4*nt + (i&3), so a lane's accumulators of the two n-tiles are 8 CONSECUTIVE
+    // output columns (one 16-byte store for 16-bit outputs, two for fp32).
+    auto set_tile = [&](int t) {
+        const int pid = xcd_remap(t, nwg);
+        const int width = GROUP_M256 * p.tiles_n;
+        const int first_m = (pid / width) * GROUP_M256;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M256);
+        m0 = (first_m + (pid % width) % gsz) * TM;
+        n0 = ((pid % width) / gsz) * TN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int lr = (wave * 2 + i) * 8 + (lane >> 3);            // local row inside the half-tile image
-        const int c = (lane & 7) ^ ((lr >> 1) & 7);
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (wave * 2 + i) * 8 + (lane >> 3);            // local row inside the half-tile image
+            const int c = (lane & 7) ^ ((lr >> 1) & 7);
+            const int fi = lr & 15, fnt = (lr >> 4) & 1;
+            const int wcol = (lr >> 5) * 64 + 8 * (fi >> 2) + 4 * fnt + (fi & 3);
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const int trow = (lr < 64 ? lr : lr + 64) + x * 64;      // A: tile row
-            const int tcol = (lr >> 5) * 64 + x * 32 + (lr & 31);    // W: tile column
-            a_off[x][i] = (unsigned)min(m0 + trow, p.M - 1) * (unsigned)(p.lda * 2) + c * 16;
-            w_off[x][i] = (unsigned)(n0 + tcol) * (unsigned)(p.K * 2) + c * 16;
+            for (int x = 0; x < 2; ++x) {
+                const int trow = (lr < 64 ? lr : lr + 64) + x * 64;      // A: tile row
+                a_off[x][i] = (unsigned)(m0 + trow) * (unsigned)(p.lda * 2) + c * 16;
+                w_off[x][i] = (unsigned)(n0 + wcol + x * 32) * (unsigned)(p.K * 2) + c * 16;
+            }
         }
-    }
+    };
     auto issue = [&](int buf, int slot, int kt) {
         char* dst = smem + (buf * 4 + slot) * HALF_BYTES + wave * 2048;
         const unsigned kb = (unsigned)kt * 128u;
@@ -100,6 +108,17 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + i * 1024), 16, 0, 0);
         }
     };
+    // K-step 0 completely, plus the two half-tiles of K-step 1 that phases (-1,2) and (-1,3) would issue
+    auto issue_prologue = [&]() {
+        issue(0, SLOT_A0, 0);
+        issue(0, SLOT_B1, 0);
+        issue(0, SLOT_A1, 0);
+        issue(0, SLOT_B0, 0);
+        if (nkt > 1) {
+            issue(1, SLOT_A0, 1);
+            issue(1, SLOT_B1, 1);
+        }
+    };
 
     // ---- fragment read offsets inside a half-tile image ----
     const int swz = (li >> 1) & 7;
@@ -110,6 +129,16 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     const int b_row0 = wc * 32 * 128;          // this wave's 32 rows inside a B half-tile
 
     f32x4 acc[2][2][4][2];                      // [A half s][B half x][m-tile][n-tile]
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+
+    // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The next tile's prologue loads are
+    // issued before the current tile's epilogue stores, so they land while the stores drain.
+    int tile = blockIdx.x;
+    set_tile(tile);
+    issue_prologue();
+    bool first = true;
+    while (true) {
+        const int cm0 = m0, cn0 = n0;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -118,21 +147,11 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[s][x][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nkt = p.K / 64;
-
-    // ---- prologue: K-step 0 completely, plus the two half-tiles of K-step 1 that phases (-1,2) and (-1,3) would issue
-    issue(0, SLOT_A0, 0);
-    issue(0, SLOT_B1, 0);
-    issue(0, SLOT_A1, 0);
-    issue(0, SLOT_B0, 0);
-    if (nkt > 1) {
-        issue(1, SLOT_A0, 1);
-        issue(1, SLOT_B1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // first tile: the two youngest half-tiles may stay in flight; later tiles: the epilogue's stores were issued
+    // after the prologue loads, so everything is drained
+    if (first && nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    first = false;
     wg_barrier();
 
     frag_t af[4][2], bf[2][2];
@@ -162,7 +181,6 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     // barriers; group 1 starts one barrier late and group 0 ends with one extra barrier.  The counted wait that
     // retires K-step t+1 sits at the end of the same global segment for both groups (end of the MFMA segment of
     // phase 3 for group 0, end of the load segment of phase 3 for group 1), one barrier before its first reader.
-    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
 #define OTTER_SEG_END()                                     \
     __builtin_amdgcn_sched_barrier(0);                      \
     wg_barrier();                                           \
@@ -211,40 +229,63 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
         OTTER_SEG_END()
     }
     if (!late) { OTTER_SEG_END() }
-#undef OTTER_SEG_END
-#undef OTTER_MFMA_SEG
-#undef OTTER_RETIRE_NEXT
-#undef OTTER_QUADRANT
 
-    // ---- epilogue: accumulator tile = D[row n][col m]; lane holds m = li, n = 4g + 0..3 ----
+    // ---- all LDS reads of this tile are complete (every load segment ends with lgkmcnt(0) before its barrier):
+    //      start the next tile's loads, then store this one ----
+    tile += gridDim.x;
+    const bool more = tile < nwg;
+    if (more) {
+        set_tile(tile);
+        issue_prologue();
+    }
+    // accumulator tile = D[row n][col m]; lane holds m = li and, over its two n-tiles, columns 8g + 0..7
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + wc * 64 + x * 32 + nt * 16 + g * 4;
-            if (n >= p.N) continue;
-            f32x4 b = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) b = *(const f32x4*)(p.bias + n);
+    for (int x = 0; x < 2; ++x) {
+        const int n = cn0 + wc * 64 + x * 32 + g * 8;
+        if (n < p.N) {
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                b0 = *(const f32x4*)(p.bias + n);
+                b1 = *(const f32x4*)(p.bias + n + 4);
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const int m = m0 + wr * 128 + s * 64 + mt * 16 + li;
-                    if (m >= p.M) continue;
-                    f32x4 v = acc[s][x][mt][nt] + b;
+                    const int m = cm0 + wr * 128 + s * 64 + mt * 16 + li;
+                    f32x4 v0 = acc[s][x][mt][0] + b0, v1 = acc[s][x][mt][1] + b1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act256<ACT>(v[e]);
-                    if (RES) v += *(const f32x4*)(p.residual + (long)m * p.ldr + n);
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] = act256<ACT>(v0[e]);
+                        v1[e] = act256<ACT>(v1[e]);
+                    }
+                    if (RES) {
+                        const float* r = p.residual + (long)m * p.ldr + n;
+                        v0 += *(const f32x4*)r;
+                        v1 += *(const f32x4*)(r + 4);
+                    }
                     if constexpr (OUT_F32) {
-                        *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
+                        float* c = (float*)p.C + (long)m * p.ldc + n;
+                        *(f32x4*)c = v0;
+                        *(f32x4*)(c + 4) = v1;
                     } else {
-                        typename Half16<T>::v4 o;
+                        typename Half16<T>::v8 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = Half16<T>::from(v[e]);
-                        *(typename Half16<T>::v4*)((T*)p.C + (long)m * p.ldc + n) = o;
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = Half16<T>::from(v0[e]);
+                            o[4 + e] = Half16<T>::from(v1[e]);
+                        }
+                        *(typename Half16<T>::v8*)((T*)p.C + (long)m * p.ldc + n) = o;
                     }
                 }
         }
+    }
+    if (!more) break;
+    }   // tile loop
+#undef OTTER_SEG_END
+#undef OTTER_MFMA_SEG
+#undef OTTER_RETIRE_NEXT
+#undef OTTER_QUADRANT
 }
 
 template <typename T, int ACT, bool OUT_F32, bool RES>
@@ -259,7 +300,18 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), LDS_BYTES, s, a);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            otter_set_error("otter_gemm (256x256): cannot query the device");
+            return OTTER_ERR_LAUNCH;
+        }
+        n_cu = prop.multiProcessorCount;
+    }
+    const int tiles = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDS_BYTES, s, a);
     OTTER_CHECK_LAUNCH("otter_gemm (256x256)");
     return OTTER_OK;
 }
@@ -280,9 +332,10 @@ int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, hipStream
 }  // namespace
 
 // Shapes the 256x256 kernel accepts (checked by the caller in gemm.hip, which owns the argument validation).
-bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K) {
+bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc) {
     if (dtype != DT_BF16 && dtype != DT_F16) return false;
     if (M < 1024 || N < 256 || K % 64 != 0) return false;                       // small problems: 128x128 tiles fill the chip better
+    if (N % 8 != 0 || ldc % 8 != 0 || ((uintptr_t)C & 15) != 0) return false;     // a lane stores 8 consecutive columns as 16-byte vectors
     if (n_pad < ((N + TN - 1) / TN) * TN) return false;                          // weight rows must cover whole 256-column tiles
     if ((long)M * lda * 2 >= (1L << 32) || (long)n_pad * K * 2 >= (1L << 32)) return false;   // 32-bit source offsets
     return true;
@@ -290,6 +343,10 @@ bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K)
 
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
                          void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s) {
+    if (M <= 0 || M % TM != 0) {                     // whole 256-row tiles only: the caller sends the remainder elsewhere
+        otter_set_error("otter_gemm (256x256): M=%d is not a positive multiple of %d", M, TM);
+        return OTTER_ERR_UNSUPPORTED_SHAPE;
+    }
     Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, (N + TN - 1) / TN};
     return dtype == DT_BF16 ? dispatch256<__bf16>(a, act, out_f32, res, s) : dispatch256<_Float16>(a, act, out_f32, res, s);
 }

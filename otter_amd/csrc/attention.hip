@@ -26,59 +26,63 @@ struct AttnArgs {
 __device__ __forceinline__ int k_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 __device__ __forceinline__ int v_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }
 
-template <typename T, int NKT>   // NKT = number of 16-key tiles the registers hold (even)
+// NT = number of 16-key tiles computed (also the number of 16-query tiles); LS = the sequence length when it is
+// known at compile time (0: taken from the arguments).  With LS the validity of every key is a compile-time fact
+// except in the last, partial tile, so the softmax carries no masking work for the full tiles.
+template <typename T, int NT, int LS>
 __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 v8;
     typedef typename Half16<T>::v4 v4;
     const T* qkv = (const T*)p.qkv;
     T* outp = (T*)p.out;
-    constexpr int LK = NKT * 16;
+    constexpr int LK = NT * 16;
+    constexpr int NP = (NT + 1) / 2;               // key-tile pairs of the second product (K = 32 per MFMA)
     char* sK = smem;
     char* sV = smem + LK * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seq = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
-    const int L = p.L;
+    const int L = LS ? LS : p.L;
+    const bool causal = LS ? false : (p.causal != 0);
     const long row0 = (long)seq * L;
     const int hd = p.heads * 64;
+    const int g = lane >> 4, li = lane & 15;
 
-    // ---- stage K and V of this head (rows >= L are zero) ----
-    for (int idx = tid; idx < LK * 8; idx += 256) {
-        const int r = idx >> 3, c = idx & 7;
-        s16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (r < L) {
-            const T* base = qkv + (row0 + r) * p.ld + h * 64 + c * 8;
-            kv = *(const s16x8*)(base + hd);
-            vv = *(const s16x8*)(base + 2 * hd);
-        }
-        *(s16x8*)(sK + r * 128 + (k_swz(r, c) << 4)) = kv;
-        *(s16x8*)(sV + r * 128 + (v_swz(r, c) << 4)) = vv;
+    // first query tile of this wave: issue its loads before the K/V staging so both latencies overlap
+    auto load_q = [&](int qt, v8 (&qf)[2]) {
+        const int qc = min(qt * 16 + li, L - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *(const v8*)(qkv + (row0 + qc) * p.ld + h * 64 + ks * 32 + g * 8);
+    };
+    v8 qf[2];
+    load_q(wave, qf);
+
+    // ---- stage K and V of this head by LDS-DMA: one instruction = 8 rows x 128 bytes, lane-linear destination, the
+    //      chunk swizzle applied on the source address.  Rows >= L repeat row L-1 (finite data; their keys are masked). ----
+    for (int grp = wave; grp < LK / 8; grp += 4) {
+        const int r = grp * 8 + (lane >> 3), pc = lane & 7;
+        const T* base = qkv + (row0 + min(r, L - 1)) * p.ld + h * 64;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + hd + (k_swz(r, pc) << 3)), LDS_PTR(sK + grp * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + 2 * hd + (v_swz(r, pc) << 3)), LDS_PTR(sV + grp * 1024), 16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int g = lane >> 4, li = lane & 15;
-    const int nkt = (L + 15) >> 4;                 // key tiles that hold real keys
-    const int nqt = nkt;
     // K fragment read: row kt*16 + li, logical chunk ks*4 + g
     const int k_row_off = li * 128;
     const int k_sw = (li >> 1) & 7;
     // V transposed read: lane li of group g addresses row r0 + (li>>2), bytes (li&3)*8 of the d-tile
     const int vr = li >> 2;
+    const float c2 = p.scale * 1.44269504088896341f;     // softmax(scale*s) = 2^(c2*s - c2*max) / sum
 
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < NT; qt += 4) {
         const int q = qt * 16 + li;                // this lane's query
-        const int qc = min(q, L - 1);
-        v8 qf[2];
+        // Every key tile is computed, also rows past L: a wave-uniform skip here would put a branch between an
+        // MFMA and the first read of its accumulator.
+        f32x4 s[NT];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[ks] = *(const v8*)(qkv + (row0 + qc) * p.ld + h * 64 + ks * 32 + g * 8);
-
-        // Every one of the NKT key tiles is computed, also those past L (their K rows are zero in LDS and the
-        // mask below removes them): a wave-uniform skip here would put a branch between an MFMA and the first
-        // read of its accumulator.
-        f32x4 s[NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+        for (int kt = 0; kt < NT; ++kt) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -86,26 +90,28 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
                 s[kt] = Half16<T>::mfma32(kf, qf[ks], s[kt]);
             }
         }
-        // ---- mask + softmax over keys (per lane: one query) ----
+        if (qt + 4 < NT) load_q(qt + 4, qf);        // lands while the softmax runs
+
+        // ---- mask + softmax over keys (per lane: one query).  Key kt*16 + 4g + r is valid iff kt*16 + r < lim. ----
+        const int lim = (causal ? min(L, q + 1) : L) - 4 * g;
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + g * 4 + r;
-                const bool ok = (key < L) && (!p.causal || key <= q);
-                const float v = ok ? s[kt][r] * p.scale : -INFINITY;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
+                const bool known_valid = LS && (kt * 16 + 15 < LS);      // every lane's key of this tile is < L
+                if (!known_valid) s[kt][r] = (kt * 16 + r < lim) ? s[kt][r] : -INFINITY;
+                mx = fmaxf(mx, s[kt][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float off = -mx * c2;
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[kt][r] - mx);     // exp(-inf) = 0 for masked keys
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, off));     // 2^(-inf) = 0 for masked keys
                 s[kt][r] = e;
                 sum += e;
             }
@@ -118,26 +124,28 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s2 = 0; s2 < NKT / 2; ++s2) {
-            {
-                v8 pf;
+        for (int s2 = 0; s2 < NP; ++s2) {
+            constexpr T zero = (T)0.0f;
+            const bool has_hi = 2 * s2 + 1 < NT;
+            v8 pf;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pf[r] = Half16<T>::from(s[2 * s2][r]);
-                    pf[4 + r] = Half16<T>::from(s[2 * s2 + 1][r]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = Half16<T>::from_unit(s[2 * s2][r]);
+                pf[4 + r] = has_hi ? Half16<T>::from_unit(s[has_hi ? 2 * s2 + 1 : 0][r]) : zero;
+            }
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int rlo = 32 * s2 + 4 * g + vr, rhi = rlo + 16;
-                    const int cl = dt * 2 + ((li & 3) >> 1), sub = (li & 1) * 8;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(sV + rlo * 128 + (v_swz(rlo, cl) << 4) + sub));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            for (int dt = 0; dt < 4; ++dt) {
+                const int rlo = 32 * s2 + 4 * g + vr, rhi = rlo + 16;
+                const int cl = dt * 2 + ((li & 3) >> 1), sub = (li & 1) * 8;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sV + rlo * 128 + (v_swz(rlo, cl) << 4) + sub));
+                s16x4 hi = {0, 0, 0, 0};
+                if (has_hi)
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(sV + rhi * 128 + (v_swz(rhi, cl) << 4) + sub));
-                    union { struct { s16x4 a, b; } h; v8 v; } u;
-                    u.h.a = lo; u.h.b = hi;
-                    o[dt] = Half16<T>::mfma32(u.v, pf, o[dt]);
-                }
+                union { struct { s16x4 a, b; } h; v8 v; } u;
+                u.h.a = lo; u.h.b = hi;
+                o[dt] = Half16<T>::mfma32(u.v, pf, o[dt]);
             }
         }
         if (q < L) {
@@ -152,10 +160,10 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
     }
 }
 
-template <typename T, int NKT>
+template <typename T, int NT, int LS>
 int launch_d64(const AttnArgs& a, int n_seq, hipStream_t s) {
-    constexpr int lds = NKT * 16 * 128 * 2;
-    auto kern = attn_d64<T, NKT>;
+    constexpr int lds = NT * 16 * 128 * 2;
+    auto kern = attn_d64<T, NT, LS>;
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -212,9 +220,10 @@ __global__ __launch_bounds__(256) void attn_policy(PolicyAttnArgs p, int total) 
 
 template <typename T>
 static int dispatch_d64(const AttnArgs& a, int n_seq, int L, hipStream_t s) {
-    if (L <= 32) return launch_d64<T, 2>(a, n_seq, s);
-    if (L <= 96) return launch_d64<T, 6>(a, n_seq, s);
-    return launch_d64<T, 18>(a, n_seq, s);
+    if (L == 257 && !a.causal) return launch_d64<T, 17, 257>(a, n_seq, s);      // ViT-L/14 and ViT-B/... at 224: 256 patches + CLS
+    if (L <= 32) return launch_d64<T, 2, 0>(a, n_seq, s);
+    if (L <= 96) return launch_d64<T, 6, 0>(a, n_seq, s);
+    return launch_d64<T, 18, 0>(a, n_seq, s);
 }
 
 extern "C" int otter_attn_fwd_d64(int dtype, const void* qkv, long ld, void* out, long ldo, int n_seq, int L, int heads,

@@ -25,6 +25,10 @@ bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K,
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
                          void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
 
+// 64x64-tile kernel for the remainder rows (gemm_tail.hip)
+int otter_gemm_tail_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+                           void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -236,15 +240,14 @@ extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int
     hipStream_t s = (hipStream_t)stream;
     if (!(epilogue & OTTER_EPI_TILE_128) && otter_gemm256_eligible(dtype, lda, n_pad, M, N, K, C, ldc)) {
         // Rows are independent: whole 256-row tiles go to the 256x256 kernel, the remaining (< 256) rows to the
-        // 128x128 kernel, so the big kernel's last round never runs mostly-empty tiles.
+        // 64x64 kernel.
         const int m_main = (M / 256) * 256;
         int rc = otter_gemm256_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, m_main, N, K, act, out_f32, res, s);
         if (rc != OTTER_OK || m_main == M) return rc;
         const long ec = (out_f32 ? 4 : es);
-        A = (const char*)A + (long)m_main * lda * es;
-        C = (char*)C + (long)m_main * ldc * ec;
-        if (res) residual += (long)m_main * ldr;
-        M -= m_main;
+        return otter_gemm_tail_launch(dtype, (const char*)A + (long)m_main * lda * es, lda, W, bias,
+                                      res ? residual + (long)m_main * ldr : nullptr, ldr, (char*)C + (long)m_main * ldc * ec, ldc,
+                                      M - m_main, N, K, act, out_f32, res, s);
     }
     const int tm = (M + BM - 1) / BM;
     GemmArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, tm, tiles_n};

@@ -1,0 +1,181 @@
+// 64x64-tile MFMA GEMM for the few remainder rows of a big 16-bit GEMM (same contract as gemm.hip).
+//
+// The 256x256 kernel takes whole 256-row tiles; the < 256 rows that remain are a latency-bound problem, so the
+// tiles are small: a 128-row remainder spreads over 32..128 CUs instead of 8..32.  (Running it beside the big
+// kernel on a second stream was measured and lost to the cross-stream fork/join cost.)
+//
+// Layout as in gemm.hip: LDS-DMA staging with the chunk swizzle on the source address, weight rows as the MFMA
+// "A" operand; the weight rows of a wave's 32 columns are permuted so that a lane's two n-tiles hold 8
+// consecutive output columns (16-byte stores), as in gemm256.hip.
+#include "common.hpp"
+#include "otter_hip.h"
+
+namespace {
+
+constexpr int TB = 64;                                   // tile edge
+constexpr int ROWB = 128;                                // bytes of K per row and K-step
+constexpr int STAGE = 2 * TB * ROWB;                     // 16 KiB
+constexpr int NS = 4;                                    // LDS stages: three K-steps in flight hide the load latency
+
+struct TailArgs {
+    const char* A; long lda;
+    const char* W;
+    const float* bias;
+    const float* residual; long ldr;
+    void* C; long ldc;
+    int M, N, K, tiles_m, tiles_n;
+};
+
+enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU = 2, ACT_RELU = 3 };
+
+template <int ACT> __device__ __forceinline__ float act_t(float v) {
+    if (ACT == ACT_QUICKGELU) return quick_gelu(v);
+    if (ACT == ACT_GELU) return gelu_erf(v);
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+
+template <typename T, int ACT, bool OUT_F32, bool RES>
+__global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Half16<T>::v8 frag_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+    const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+    const int m0 = tm * TB, n0 = tn * TB;
+
+    // staging: a stage is 128 image rows (64 of A, then 64 of W) = 16 instructions of 8 rows; wave w issues 4w..4w+3
+    // (waves 0,1 fetch A, waves 2,3 fetch W)
+    unsigned src_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ir = (wave * 4 + i) * 8 + (lane >> 3);           // image row 0..127
+        const int r = ir & 63;
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        if (wave < 2) {
+            src_off[i] = (unsigned)min(m0 + r, p.M - 1) * (unsigned)(p.lda * 2) + c * 16;
+        } else {
+            const int fi = r & 15, fnt = (r >> 4) & 1;
+            const int col = (r >> 5) * 32 + 8 * (fi >> 2) + 4 * fnt + (fi & 3);
+            src_off[i] = (unsigned)(n0 + col) * (unsigned)(p.K * 2) + c * 16;
+        }
+    }
+    const char* src_base = wave < 2 ? p.A : p.W;
+    auto stage = [&](int buf, unsigned kbyte) {
+        char* dst = smem + buf * STAGE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src_base + (src_off[i] + kbyte)), LDS_PTR(dst + i * 1024), 16, 0, 0);
+    };
+
+    const int swz = (li >> 1) & 7;
+    const int row_off = li * ROWB;
+
+    f32x4 acc[2][2];                                    // [m-tile][n-tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) stage(t, (unsigned)t * ROWB);
+    for (int t = 0; t < nk; ++t) {
+        // stages t .. t+NS-2 have been issued (4 instructions each per thread): retire stage t only
+        if (t + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");           // stage t visible to all waves; everyone is done with stage t-1
+        if (t + NS - 1 < nk) stage((t + NS - 1) % NS, (unsigned)(t + NS - 1) * ROWB);
+        const int cur = t % NS;
+        const char* sA = smem + cur * STAGE + wm * 32 * ROWB;
+        const char* sW = smem + cur * STAGE + TB * ROWB + wn * 32 * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = row_off + (((ks * 4 + g) ^ swz) << 4);
+            frag_t wf[2], af[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = *(const frag_t*)(sW + j * 16 * ROWB + off);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const frag_t*)(sA + i * 16 * ROWB + off);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(wf[j], af[i], acc[i][j]);
+        }
+    }
+
+    // epilogue: lane holds row m = li (per m-tile) and columns 8g + 0..7 of the wave's 32
+    const int n = n0 + wn * 32 + g * 8;
+    if (n >= p.N) return;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        b0 = *(const f32x4*)(p.bias + n);
+        b1 = *(const f32x4*)(p.bias + n + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + li;
+        if (m >= p.M) continue;
+        f32x4 v0 = acc[i][0] + b0, v1 = acc[i][1] + b1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = act_t<ACT>(v0[e]);
+            v1[e] = act_t<ACT>(v1[e]);
+        }
+        if (RES) {
+            const float* r = p.residual + (long)m * p.ldr + n;
+            v0 += *(const f32x4*)r;
+            v1 += *(const f32x4*)(r + 4);
+        }
+        if constexpr (OUT_F32) {
+            float* c = (float*)p.C + (long)m * p.ldc + n;
+            *(f32x4*)c = v0;
+            *(f32x4*)(c + 4) = v1;
+        } else {
+            typename Half16<T>::v8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = Half16<T>::from(v0[e]);
+                o[4 + e] = Half16<T>::from(v1[e]);
+            }
+            *(typename Half16<T>::v8*)((T*)p.C + (long)m * p.ldc + n) = o;
+        }
+    }
+}
+
+template <typename T, int ACT, bool OUT_F32, bool RES>
+int launch_tail(const TailArgs& a, hipStream_t s) {
+    auto kern = gemm_64x64<T, ACT, OUT_F32, RES>;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE);
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), NS * STAGE, s, a);
+    OTTER_CHECK_LAUNCH("otter_gemm (64x64)");
+    return OTTER_OK;
+}
+
+template <typename T>
+int dispatch_tail(const TailArgs& a, int act, bool out_f32, bool res, hipStream_t s) {
+    if (res) return launch_tail<T, ACT_NONE, true, true>(a, s);
+    switch (act) {
+        case OTTER_EPI_ACT_NONE: return out_f32 ? launch_tail<T, ACT_NONE, true, false>(a, s) : launch_tail<T, ACT_NONE, false, false>(a, s);
+        case OTTER_EPI_ACT_QUICKGELU: return out_f32 ? launch_tail<T, ACT_QUICKGELU, true, false>(a, s) : launch_tail<T, ACT_QUICKGELU, false, false>(a, s);
+        case OTTER_EPI_ACT_GELU: return out_f32 ? launch_tail<T, ACT_GELU, true, false>(a, s) : launch_tail<T, ACT_GELU, false, false>(a, s);
+        case OTTER_EPI_ACT_RELU: return out_f32 ? launch_tail<T, ACT_RELU, true, false>(a, s) : launch_tail<T, ACT_RELU, false, false>(a, s);
+    }
+    otter_set_error("otter_gemm: unknown activation %d", act);
+    return OTTER_ERR_INVALID_ARGUMENT;
+}
+
+}  // namespace
+
+// Remainder rows (M < 256) of a GEMM whose whole 256-row tiles run in the 256x256 kernel.
+int otter_gemm_tail_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+                           void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s) {
+    TailArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB};
+    return dtype == DT_BF16 ? dispatch_tail<__bf16>(a, act, out_f32, res, s) : dispatch_tail<_Float16>(a, act, out_f32, res, s);
+}

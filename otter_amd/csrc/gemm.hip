@@ -25,9 +25,10 @@ bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K,
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
                          void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
 
-// 64x64-tile kernel for the remainder rows (gemm_tail.hip)
-int otter_gemm_tail_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
-                           void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
+// 64x64-tile kernel for remainder rows and small problems (gemm_tail.hip)
+bool otter_gemm64_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc);
+int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+                        void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
 
 namespace {
 
@@ -245,10 +246,13 @@ extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int
         int rc = otter_gemm256_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, m_main, N, K, act, out_f32, res, s);
         if (rc != OTTER_OK || m_main == M) return rc;
         const long ec = (out_f32 ? 4 : es);
-        return otter_gemm_tail_launch(dtype, (const char*)A + (long)m_main * lda * es, lda, W, bias,
+        return otter_gemm64_launch(dtype, (const char*)A + (long)m_main * lda * es, lda, W, bias,
                                       res ? residual + (long)m_main * ldr : nullptr, ldr, (char*)C + (long)m_main * ldc * ec, ldc,
                                       M - m_main, N, K, act, out_f32, res, s);
     }
+    // too few 128x128 tiles to give every CU one: the 64x64 kernel spreads the problem over 4x more workgroups
+    if (!(epilogue & OTTER_EPI_TILE_128) && (long)tiles_m * tiles_n < 256 && otter_gemm64_eligible(dtype, lda, n_pad, M, N, K, C, ldc))
+        return otter_gemm64_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, M, N, K, act, out_f32, res, s);
     const int tm = (M + BM - 1) / BM;
     GemmArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, tm, tiles_n};
     if (dtype == DT_BF16) return dispatch<__bf16>(a, act, out_f32, res, s);

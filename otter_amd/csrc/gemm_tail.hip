@@ -1,8 +1,9 @@
-// 64x64-tile MFMA GEMM for the few remainder rows of a big 16-bit GEMM (same contract as gemm.hip).
-//
-// The 256x256 kernel takes whole 256-row tiles; the < 256 rows that remain are a latency-bound problem, so the
-// tiles are small: a 128-row remainder spreads over 32..128 CUs instead of 8..32.  (Running it beside the big
-// kernel on a second stream was measured and lost to the cross-stream fork/join cost.)
+// 64x64-tile MFMA GEMM for small problems (same contract as gemm.hip; bf16 / fp16 / fp32 operands):
+//   * the < 256 remainder rows of a big 16-bit GEMM whose whole 256-row tiles run in the 256x256 kernel (running
+//     them beside the big kernel on a second stream was measured and lost to the cross-stream fork/join cost);
+//   * any GEMM too small to give the 128x128 kernel one tile per CU (policy transformer, pooling projections, heads).
+// Such problems are latency-bound: small tiles spread them over 4x more CUs and four LDS stages keep three
+// K-steps of loads in flight per workgroup.
 //
 // Layout as in gemm.hip: LDS-DMA staging with the chunk swizzle on the source address, weight rows as the MFMA
 // "A" operand; the weight rows of a wave's 32 columns are permuted so that a lane's two n-tiles hold 8
@@ -35,10 +36,25 @@ template <int ACT> __device__ __forceinline__ float act_t(float v) {
     return v;
 }
 
+template <typename T> struct TFrag { typedef typename Half16<T>::v8 type; };
+template <> struct TFrag<float> { typedef f32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ f32x4 mma_t(const typename TFrag<T>::type& w, const typename TFrag<T>::type& a, f32x4 c) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], a[e], c, 0, 0, 0);
+        return c;
+    } else {
+        return Half16<T>::mfma32(w, a, c);
+    }
+}
+
 template <typename T, int ACT, bool OUT_F32, bool RES>
 __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename Half16<T>::v8 frag_t;
+    typedef typename TFrag<T>::type frag_t;
+    constexpr int ES = sizeof(T);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
     const int g = lane >> 4, li = lane & 15;
@@ -54,11 +70,11 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
         const int r = ir & 63;
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         if (wave < 2) {
-            src_off[i] = (unsigned)min(m0 + r, p.M - 1) * (unsigned)(p.lda * 2) + c * 16;
+            src_off[i] = (unsigned)min(m0 + r, p.M - 1) * (unsigned)(p.lda * ES) + c * 16;
         } else {
             const int fi = r & 15, fnt = (r >> 4) & 1;
             const int col = (r >> 5) * 32 + 8 * (fi >> 2) + 4 * fnt + (fi & 3);
-            src_off[i] = (unsigned)(n0 + col) * (unsigned)(p.K * 2) + c * 16;
+            src_off[i] = (unsigned)(n0 + col) * (unsigned)(p.K * ES) + c * 16;
         }
     }
     const char* src_base = wave < 2 ? p.A : p.W;
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / 64;
+    const int nk = p.K * ES / ROWB;
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) stage(t, (unsigned)t * ROWB);
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(wf[j], af[i], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma_t<T>(wf[j], af[i], acc[i][j]);
         }
     }
 
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
             v0 += *(const f32x4*)r;
             v1 += *(const f32x4*)(r + 4);
         }
-        if constexpr (OUT_F32) {
+        if constexpr (OUT_F32 || sizeof(T) == 4) {
             float* c = (float*)p.C + (long)m * p.ldc + n;
             *(f32x4*)c = v0;
             *(f32x4*)(c + 4) = v1;
@@ -158,6 +174,21 @@ int launch_tail(const TailArgs& a, hipStream_t s) {
     return OTTER_OK;
 }
 
+template <int ACT>
+int launch_tail_f32(const TailArgs& a, hipStream_t s) { return launch_tail<float, ACT, true, false>(a, s); }
+
+int dispatch_tail_f32(const TailArgs& a, int act, bool res, hipStream_t s) {
+    if (res) return launch_tail<float, ACT_NONE, true, true>(a, s);
+    switch (act) {
+        case OTTER_EPI_ACT_NONE: return launch_tail_f32<ACT_NONE>(a, s);
+        case OTTER_EPI_ACT_QUICKGELU: return launch_tail_f32<ACT_QUICKGELU>(a, s);
+        case OTTER_EPI_ACT_GELU: return launch_tail_f32<ACT_GELU>(a, s);
+        case OTTER_EPI_ACT_RELU: return launch_tail_f32<ACT_RELU>(a, s);
+    }
+    otter_set_error("otter_gemm: unknown activation %d", act);
+    return OTTER_ERR_INVALID_ARGUMENT;
+}
+
 template <typename T>
 int dispatch_tail(const TailArgs& a, int act, bool out_f32, bool res, hipStream_t s) {
     if (res) return launch_tail<T, ACT_NONE, true, true>(a, s);
@@ -173,9 +204,18 @@ int dispatch_tail(const TailArgs& a, int act, bool out_f32, bool res, hipStream_
 
 }  // namespace
 
-// Remainder rows (M < 256) of a GEMM whose whole 256-row tiles run in the 256x256 kernel.
-int otter_gemm_tail_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
-                           void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s) {
+// Shapes the 64x64 kernel accepts: 8-column vector stores and 32-bit source offsets.
+bool otter_gemm64_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc) {
+    const long es = dtype == DT_F32 ? 4 : 2;
+    if (N % 8 != 0 || ((uintptr_t)C & 15) != 0) return false;
+    if (ldc % (dtype == DT_F32 ? 4 : 8) != 0) return false;                       // 16-bit outputs are stored 8 at a time; fp32 ones 4 at a time
+    if (n_pad < ((N + TB - 1) / TB) * TB) return false;
+    return (long)M * lda * es < (1L << 32) && (long)n_pad * K * es < (1L << 32);
+}
+
+int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+                        void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s) {
     TailArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB};
+    if (dtype == DT_F32) return dispatch_tail_f32(a, act, res, s);
     return dtype == DT_BF16 ? dispatch_tail<__bf16>(a, act, out_f32, res, s) : dispatch_tail<_Float16>(a, act, out_f32, res, s);
 }

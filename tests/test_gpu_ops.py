@@ -78,6 +78,23 @@ def test_gemm(dev, m, n, k, act, out_f32, dtype):
     torch.testing.assert_close(out.float(), ref, **tol)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("m,n,k", [(300, 256, 128), (129, 120, 1536), (1000, 3072, 1024)])
+def test_gemm_128_tile_kernel(dev, m, n, k, dtype):
+    """The 128x128 kernel on shapes the dispatcher would give to the 64x64 / 256x256 kernels: same results."""
+    from otter_amd import ops
+    dt = DTYPES[dtype]
+    a = _randn(11, m, k).to(dev).to(dt)
+    w = (_randn(12, n, k) / math.sqrt(k)).to(dev)
+    bias = _randn(13, n).to(dev)
+    wp = ops.pack_weight(w, dt)
+    res = _randn(14, m, n).to(dev)
+    for kw in (dict(act=ACTS["gelu"]), dict(residual=res)):
+        ref = ops.gemm(a, wp, n, bias, **kw)
+        out = ops.gemm(a, wp, n, bias, force_tile_128=True, **kw)
+        assert torch.equal(out, ref)              # same products, same fp32 accumulation order along K
+
+
 @pytest.mark.parametrize("m", [777, 1300])          # 128-row tiles only / 256-row tiles plus a 128-row-tile remainder
 def test_gemm_residual_strided_inplace(dev, m):
     from otter_amd import ops

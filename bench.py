@@ -5,7 +5,7 @@
 
 A step = one pass of the hot path over one batch of synthetic observations: per GPU 64 concurrent episodes, each
 observation two 224x224 uint8 camera images + a tokenised prompt + a 10-d proprio vector -> a (12, 10) action chunk,
-bf16 MFMA compute, history window 12 with the GPU-resident K/V cache (episodes restart every 24 steps, so the timed
+16-bit MFMA towers + fp32 MFMA policy, history window 12 with the GPU-resident K/V cache (episodes restart every 24 steps, so the timed
 steps cover the cached fill phase and the recompute-after-slide phase; the text tower runs once per episode).
 Inputs are resident in HBM before the timed region.  One process per GPU (torchrun for N > 1), observations sharded
 by episode, no collective on the data path; value = observations of all ranks / max-over-ranks time.
@@ -200,7 +200,7 @@ def main():
             gm = k["gemm"]
             # dominant kernel: the bf16 MFMA GEMM (CLIP tower launches are >99.9% of its FLOPs)
             tf = gm["total_work"] / (gm["total_ms"] * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "kernel": "gemm_128x128 (16-bit operands, CLIP towers)", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
+            result["roofline"] = {"bound": "mfma", "kernel": "gemm_256x256 + remainder-row gemm_64x64 (16-bit operands, CLIP towers)", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
                                   "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": None,
                                   "launches": gm["launches"], "avg_launch_us": 1e3 * gm["total_ms"] / gm["launches"],
                                   "gemm_ms_per_step": gm["total_ms"] / 2}

@@ -1,7 +1,7 @@
 // Attention-pooling readout: the query side of the cross-attention blocks that compress (nk x D_in) tokens
 // into R readout vectors of width d.  The key/value projections (the only part with real FLOPs) are done by
-// the bf16 GEMM beforehand; this kernel does everything else of the pooling module in fp32, one workgroup
-// per observation, with all intermediates in LDS:
+// the GEMM beforehand; this kernel does everything else of the pooling module in fp32, one workgroup
+// per observation, with all intermediates and the block's weights in LDS:
 //   per block:  qn = LN_q(q);  Q = qn Wq^T + bq;  scores = Q K^T / sqrt(hd) (+ key padding mask);
 //               softmax over keys;  ctx = P V;  q1 = qn + ctx Wo^T + bo;      (residual on the NORMALISED query)
 //               out = q1 + fc2(gelu(fc1(LN(q1))))
@@ -35,37 +35,57 @@ __device__ __forceinline__ void ln_row(const float* in, float* out, const float*
     for (int i = lane; i < d; i += 64) out[i] = (in[i] - mean) * rstd * w[i] + b[i];
 }
 
+// Bulk copy of n floats (global -> LDS) by the whole workgroup: whole KiB pieces by LDS-DMA (one wave-instruction
+// each, nothing held in registers, all pieces in flight at once), the remainder by plain loads.  The caller
+// synchronises (s_waitcnt vmcnt(0) + barrier, both in __syncthreads()) before reading dst.
+__device__ __forceinline__ void stage_floats(float* dst, const float* src, int n, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int pieces = (((uintptr_t)src & 15) == 0) ? n / 256 : 0;          // 256 floats = 1 KiB
+    for (int c = wave; c < pieces; c += 4)
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + c * 256 + lane * 4), LDS_PTR(dst + c * 256), 16, 0, 0);
+    for (int i = pieces * 256 + tid; i < n; i += 256) dst[i] = src[i];
+}
+
+// Weights of a cross-attention block are shared by every observation and small (d*d and d*hidden floats), so each
+// workgroup copies them into LDS in bulk -- one memory latency per matrix instead of one per inner-loop step --
+// and the matrix-vector products then run at LDS speed.
 __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = blockIdx.x;
     const int R = p.R, d = p.d, nk = p.nk, heads = p.heads, hd = d / heads, hidden = p.hidden;
     const int Rd = R * d;
-    float* q = sm;                    // [R][d] running query
+    float* wS = sm;                   // [2][d][d]      Wq^T | Wo^T of the current block      (16-byte aligned: first)
+    float* wF = wS + 2 * d * d;       // [d][hidden]    fc1^T, then fc2^T
+    float* KV = wF + d * hidden;      // [nk][2d]
+    float* q = KV + nk * 2 * d;       // [R][d] running query
     float* qn = q + Rd;               // [R][d]
-    float* Q = qn + Rd;               // [R][d]  (later reused for ctx)
+    float* Q = qn + Rd;               // [R][d]
     float* q1 = Q + Rd;               // [R][d]
     float* hn = q1 + Rd;              // [R][d]
-    float* KV = hn + Rd;              // [nk][2d]
-    float* sc = KV + nk * 2 * d;      // [R][heads][nk]
+    float* sc = hn + Rd;              // [R][heads][nk]
     float* h1 = sc + R * heads * nk;  // [R][hidden]
 
     for (int i = tid; i < Rd; i += 256) q[i] = p.query[i];
-    __syncthreads();
 
     for (int b = 0; b < p.n_blocks; ++b) {
         const otter_readout_block& w = p.blk[b];
-        for (int r = wave; r < R; r += 4) ln_row(q + r * d, qn + r * d, w.q_ln_w, w.q_ln_b, d, lane);
-        // K | V of this observation and block
+        // every weight of the block's attention half, fc1 and this observation's K | V rows: all loads in flight together
+        stage_floats(wS, w.wq_t, d * d, tid);
+        stage_floats(wS + d * d, w.wo_t, d * d, tid);
+        stage_floats(wF, w.fc1_t, d * hidden, tid);
         for (int i = tid; i < nk * 2 * d; i += 256) {
             const int k = i / (2 * d), c = i % (2 * d);
             KV[i] = p.kv[((long)m * nk + k) * p.ldkv + b * 2 * d + c];
         }
+        __syncthreads();                                    // q complete (previous iteration / initial copy)
+        for (int r = wave; r < R; r += 4) ln_row(q + r * d, qn + r * d, w.q_ln_w, w.q_ln_b, d, lane);
         __syncthreads();
         for (int o = tid; o < Rd; o += 256) {
             const int r = o / d, j = o % d;
             float acc = w.bq[j];
-            for (int i = 0; i < d; ++i) acc += qn[r * d + i] * w.wq_t[i * d + j];
+#pragma unroll 8
+            for (int i = 0; i < d; ++i) acc += qn[r * d + i] * wS[i * d + j];
             Q[o] = acc;
         }
         __syncthreads();
@@ -89,7 +109,7 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs p) {
             for (int k = 0; k < nk; ++k) row[k] *= inv;
         }
         __syncthreads();
-        for (int o = tid; o < Rd; o += 256) {            // ctx -> Q (Q is dead)
+        for (int o = tid; o < Rd; o += 256) {
             const int r = o / d, j = o % d, h = j / hd;
             float acc = 0.f;
             for (int k = 0; k < nk; ++k) acc += sc[(r * heads + h) * nk + k] * KV[k * 2 * d + d + j];
@@ -99,7 +119,8 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs p) {
         for (int o = tid; o < Rd; o += 256) {
             const int r = o / d, j = o % d;
             float acc = w.bo[j];
-            for (int i = 0; i < d; ++i) acc += hn[r * d + i] * w.wo_t[i * d + j];
+#pragma unroll 8
+            for (int i = 0; i < d; ++i) acc += hn[r * d + i] * wS[d * d + i * d + j];
             q1[o] = qn[o] + acc;
         }
         __syncthreads();
@@ -108,14 +129,18 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs p) {
         for (int o = tid; o < R * hidden; o += 256) {
             const int r = o / hidden, u = o % hidden;
             float acc = w.fc1_b[u];
-            for (int i = 0; i < d; ++i) acc += hn[r * d + i] * w.fc1_t[i * hidden + u];
+#pragma unroll 8
+            for (int i = 0; i < d; ++i) acc += hn[r * d + i] * wF[i * hidden + u];
             h1[o] = gelu_erf(acc);
         }
+        __syncthreads();                                    // fc1^T is dead: fc2^T takes its place
+        stage_floats(wF, w.fc2_t, hidden * d, tid);
         __syncthreads();
         for (int o = tid; o < Rd; o += 256) {
             const int r = o / d, j = o % d;
             float acc = w.fc2_b[j];
-            for (int u = 0; u < hidden; ++u) acc += h1[r * hidden + u] * w.fc2_t[u * d + j];
+#pragma unroll 8
+            for (int u = 0; u < hidden; ++u) acc += h1[r * hidden + u] * wF[u * d + j];
             q[o] = q1[o] + acc;
         }
         __syncthreads();
@@ -147,8 +172,19 @@ extern "C" int otter_readout_pool_fwd(const otter_readout_block* blocks, int n_b
     a.n_blocks = n_blocks; a.query = query; a.final_ln_w = final_ln_w; a.final_ln_b = final_ln_b;
     a.kv = kv; a.ldkv = ldkv; a.mask = mask; a.out = out; a.ldo = ldo;
     a.M = n_obs; a.nk = nk; a.R = readouts; a.d = d; a.heads = heads; a.hidden = hidden;
-    const size_t lds = sizeof(float) * ((size_t)5 * readouts * d + (size_t)nk * 2 * d + (size_t)readouts * heads * nk + (size_t)readouts * hidden);
-    OTTER_REQUIRE(lds <= 64 * 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: needs %zu bytes of LDS (> 64 KiB)", lds);
+    const size_t lds = sizeof(float) * ((size_t)2 * d * d + (size_t)d * hidden + (size_t)5 * readouts * d + (size_t)nk * 2 * d +
+                                       (size_t)readouts * heads * nk + (size_t)readouts * hidden);
+    OTTER_REQUIRE(lds <= 160 * 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: needs %zu bytes of LDS (> 160 KiB)", lds);
+    OTTER_REQUIRE((d * d) % 4 == 0 && (d * hidden) % 4 == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: d*d and d*hidden must be multiples of 4");
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)readout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            otter_set_error("otter_readout_pool_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return OTTER_ERR_LAUNCH;
+        }
+        configured = lds;
+    }
     hipLaunchKernelGGL(readout_kernel, dim3(n_obs), dim3(256), lds, (hipStream_t)stream, a);
     OTTER_CHECK_LAUNCH("otter_readout_pool_fwd");
     return OTTER_OK;

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, long ld
         const float b = bias ? bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) acc[r] = b;
-        for (int k = 0; k < K; ++k) {
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) {                 // 8 independent weight loads in flight per thread
             const float w = wt[(long)k * N + n];
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] += xs[r * K + k] * w;

@@ -1,23 +1,26 @@
 // Fused text-aware visual extraction (memory-bound; one pass over the patch tokens).
 //
-// Per unit (observation m, camera c):   patches X (P x D, bf16, un-normalised), text T (K<=16 rows x D, fp32)
+// Per unit (observation m, camera c):   patches X (P x D, bf16 or fp16, un-normalised), text T (K<=16 rows x D, fp32)
 //   S    = T^ . X^^T              cosine similarity (T^, X^ = L2-normalised rows)
 //   A    = softmax_over_patches(S / clamp(temperature, 0, 100))
 //   out  = A . (X^ + pos_emb)     (K x D, fp32)
 //
-// One workgroup (4 waves) per unit, 2 workgroups per CU.  The patch tokens stream HBM -> LDS exactly once, in
-// 16-patch tiles by LDS-DMA (global_load_lds_dwordx4) into two buffers, so the next tile is in flight while
-// the current one is consumed.  Per tile:
-//   * S^T tile (patch x text) and the Gram diagonal |x|^2 come from v_mfma_f32_16x16x32_bf16 over D
-//     (every wave computes the same 16x16 tile: no cross-wave exchange, identical softmax state in all waves);
+// One workgroup (4 waves) per unit, one workgroup per CU.  The patch tokens stream HBM -> LDS exactly once, in
+// 16-patch tiles by LDS-DMA (global_load_lds_dwordx4) through three buffers, so two tiles are in flight behind
+// the one being consumed and the only wait per tile is a counted s_waitcnt.  Per tile:
+//   * S^T tile (patch x text) and the Gram diagonal |x|^2 come from v_mfma_f32_16x16x32 over D; each wave
+//     reduces its quarter of D and the four partial tiles are summed through LDS (identical softmax state in
+//     all waves afterwards);
 //   * online softmax over patches (running max / sum per text token, one text token per lane);
-//   * O^T += X^T . (p/|x|)  +  pos^T . p   with v_mfma_f32_16x16x16_bf16: the S^T accumulator layout
+//   * O^T += X^T . (p/|x|)  +  pos^T . p   with v_mfma_f32_16x16x16: the S^T accumulator layout
 //     (patch 4g+r on the registers, text token on the lane) is exactly that instruction's B operand, X^T comes
-//     from the row-major LDS tile by ds_read_b64_tr_b16, and pos^T is a pre-transposed bf16 table read from L2.
-//     Each wave owns D/4 output columns.
+//     from the row-major LDS tile by ds_read_b64_tr_b16, and pos^T is a pre-transposed 16-bit table read from L2
+//     (loads issued at the top of the tile, used at its end).  Each wave owns D/4 output columns.
 // LDS rows are D*2 bytes (a multiple of 256), so the 16-byte chunk index is XORed with f(row) (below) which
 // makes both the ds_read_b128 fragment reads and the transposed reads bank-conflict free.  The LDS image is
 // lane-linear (LDS-DMA requirement); the swizzle is applied to the per-lane source address.
+#include <type_traits>
+
 #include "common.hpp"
 #include "otter_hip.h"
 
@@ -41,7 +44,7 @@ __device__ __forceinline__ int f_swz(int r) {
 }
 
 template <typename T, int NDT>   // D = NDT * 64; each wave owns NDT d-tiles of 16 columns
-__global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
+__global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 v8;
     typedef typename Half16<T>::v4 v4;
@@ -49,9 +52,12 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
     constexpr int ROWB = D * 2;                 // bytes per LDS row
     constexpr int TILE_B = 16 * ROWB;           // one 16-row image
     constexpr int CPR = D / 8;                  // 16-byte chunks per row
-    constexpr int NLD = TILE_B / (256 * 16);    // LDS-DMA instructions per wave per tile
+    constexpr int NLD = TILE_B / (256 * 16);    // LDS-DMA instructions per thread per tile
+    constexpr int NST = 3;                      // patch-tile stages: two tiles in flight behind the one being consumed
+    constexpr int KSW = D / 32 / 4;             // K-steps (32 columns) of the similarity product per wave
     char* sT = smem;
     char* sX = smem + TILE_B;
+    float* sP = (float*)(smem + (1 + NST) * TILE_B);       // [2][4 waves][64 lanes][8]: partial S^T and Gram tiles
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -77,8 +83,9 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + src_off[i]), LDS_PTR(dst + (wave * NLD + i) * 1024), 16, 0, 0);
     };
     stage(0, 0);
+    if (nt > 1) stage(1, 1);
 
-    // ---- text rows: L2-normalise in fp32, store bf16 (swizzled) ; rows >= K are zero ----
+    // ---- text rows: L2-normalise in fp32, store as 16-bit (swizzled) ; rows >= K are zero ----
     {
         const int b = m / p.t_rep;
         for (int rr = 0; rr < 4; ++rr) {
@@ -123,29 +130,55 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
     const int tr_fsw = f_swz(tr_row);
     const int tr_sub = (li & 1) * 8;
 
-    __syncthreads();   // tile 0 and the text image are in LDS
+    // One tile.  PREFETCH (compile-time): tile t+2 exists and is fetched; keeping it out of a runtime branch lets the
+    // compiler count the loads in flight, so its wait for the pos^T loads does not drain the prefetch.
+    auto tile_step = [&](int t, auto prefetch_tag, auto more_tag) {
+        constexpr bool PREFETCH = decltype(prefetch_tag)::value, MORE = decltype(more_tag)::value;
+        // Tile t has landed once all but the youngest tile's loads are done (vector-memory operations retire in
+        // issue order; the pos^T loads of the previous iteration were consumed there).  The barrier also tells
+        // that every wave is done with tile t-1, whose buffer tile t+2 is about to overwrite.
+        if constexpr (MORE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");     // tile t+1 may still be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const char* xb = sX + (t % NST) * TILE_B;
 
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) stage(cur ^ 1, t + 1);
-        const char* xb = sX + cur * TILE_B;
+        // pos^T of this tile for the wave's columns (L2-resident table): issued first, consumed after the similarity phase
+        // (issued from inline asm: the compiler would wait for them with vmcnt(0), draining the tile prefetch that is
+        //  issued right after; the counted wait before their first use is placed by hand below)
+        s16x4 pt[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const T* src = posT + (long)((wave * NDT + dt) * 16 + li) * P + t * 16 + 4 * g;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pt[dt]) : "v"(src) : "memory");
+        }
+        if constexpr (PREFETCH) stage((t + 2) % NST, t + 2);
 
-        // ---- S^T (patch x text) and Gram diagonal over D ----
+        // ---- partial S^T (patch x text) and Gram diagonal over this wave's quarter of D ----
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, gd = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int ks = 0; ks < D / 32; ++ks) {
+#pragma unroll
+        for (int kk = 0; kk < KSW; ++kk) {
+            const int ks = wave * KSW + kk;
             const int coff = (((ks * 4 + g) ^ fsw) << 4);
             const v8 xf = *(const v8*)(xb + frag_row + coff);
             const v8 tf = *(const v8*)(sT + frag_row + coff);
             s = Half16<T>::mfma32(xf, tf, s);
             gd = Half16<T>::mfma32(xf, xf, gd);
         }
-        // |x|^2 of patch 4g+r sits on lane (g, li = 4g+r), register r
+        float* pp = sP + (t & 1) * 2048;
+        *(f32x4*)(pp + (wave * 64 + lane) * 8) = s;
+        *(f32x4*)(pp + (wave * 64 + lane) * 8 + 4) = gd;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += *(const f32x4*)(pp + (w * 64 + lane) * 8);
+        // |x|^2 of patch 4g+r sits on lane (g, li = 4g+r), Gram register r, of every wave's partial
         float a1[4], a2[4];
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float n2 = __shfl(gd[r], g * 16 + 4 * g + r, 64);
+            float n2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) n2 += pp[(w * 64 + g * 16 + 4 * g + r) * 8 + 4 + r];
             const float rn = 1.0f / sqrtf(n2);
             a1[r] = rn;
             a2[r] = s[r] * rn * inv_temp;                 // logit of (patch 4g+r, text li)
@@ -170,17 +203,38 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
         for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
 
         // ---- O^T += X^T (p/|x|) + pos^T p ----
+        // the pos^T loads are older than the NLD prefetch instructions issued after them (in-order retirement);
+        // the "+v" operands tie every later use of pt[] to this wait
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            if constexpr (PREFETCH) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pt[dt]) : "n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pt[dt]) : : "memory");
+        }
+        // X^T fragments by ds_read_b64_tr_b16, also from inline asm: after an LDS-DMA the compiler puts vmcnt(0) in
+        // front of the builtin form of this read (it cannot tell that the buffers differ), draining the prefetch
+        s16x4 xt[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             const int d0 = (wave * NDT + dt) * 16;
             const int chunk = (d0 >> 3) + ((li & 3) >> 1);
-            const s16x4 xt = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(xb + tr_row * ROWB + ((chunk ^ tr_fsw) << 4) + tr_sub));
-            const s16x4 pt = *(const s16x4*)(posT + (long)(d0 + li) * P + t * 16 + 4 * g);
-            o[dt] = Half16<T>::mfma16(xt, b1, o[dt]);
-            o[dt] = Half16<T>::mfma16(pt, b2, o[dt]);
+            const unsigned addr = (unsigned)(uintptr_t)LDS_PTR(xb + tr_row * ROWB + ((chunk ^ tr_fsw) << 4) + tr_sub);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xt[dt]) : "v"(addr) : "memory");
         }
-        __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done with this buffer
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xt[dt]) : : "memory");
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            o[dt] = Half16<T>::mfma16(xt[dt], b1, o[dt]);
+            o[dt] = Half16<T>::mfma16(pt[dt], b2, o[dt]);
+        }
+    };
+    {
+        using Y = std::true_type;
+        using N = std::false_type;
+        int t = 0;
+        for (; t + 2 < nt; ++t) tile_step(t, Y{}, Y{});
+        if (t + 1 < nt) { tile_step(t, N{}, Y{}); ++t; }
+        if (t < nt) tile_step(t, N{}, N{});
     }
 
     run_sum += __shfl_xor(run_sum, 16, 64);
@@ -198,11 +252,15 @@ __global__ __launch_bounds__(256, 2) void tave_kernel(TaveArgs p) {
 
 template <typename T, int NDT>
 int launch_tave(const TaveArgs& a, hipStream_t s) {
-    constexpr int lds = 3 * 16 * NDT * 64 * 2;
+    constexpr int lds = 4 * 16 * NDT * 64 * 2 + 2 * 4 * 64 * 8 * 4;       // text image + 3 patch tiles + partial-tile exchange
     auto kern = tave_kernel<T, NDT>;
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            otter_set_error("otter_text_aware_pool_fwd: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
+            return OTTER_ERR_LAUNCH;
+        }
         configured = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.units), dim3(256), lds, s, a);

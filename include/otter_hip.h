@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 2
+#define OTTER_HIP_ABI_VERSION 3
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -148,6 +148,67 @@ int otter_add_pe(const float* window, const float* pe, float* out, int batch, in
  * (ping-pong) buffers; window rows beyond an episode's length are zero. */
 int otter_window_append(const float* src, const float* fresh, float* dst, const int* lens_in, int* lens_out, int batch,
                         int window_len, int dim, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Training step (fp32): forward pieces with saved pre-activations and hand-written backward of the trainable
+ * modules (everything but CLIP, otter/policy/otter.py:75-128), loss, gradient statistics and AdamW.
+ * The reference gets these from torch autograd + torch.optim (otter/util/engine.py:44-66, misc.py:329-348,
+ * script/train.py:168-171).  Kernels that produce gradients ACCUMULATE (+=) into zero-initialised buffers.
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* C[M,N] (+)= op(A)[M,K] . op(B)[K,N] (+ bias[n]) with element strides: A(m,k) = A[m*sa_m + k*sa_k],
+ * B(k,n) = B[k*sb_k + n*sb_n].  nn.Linear forward (transformer.py:38-50, models.py:42-66): A = x, B = W^T
+ * (sb_k = 1, sb_n = ldw); input gradient dy.W: sb_k = ldw, sb_n = 1; weight gradient dy^T.x: sa_m = 1, sa_k = ld_dy. */
+int otter_sgemm_strided(const float* A, long sa_m, long sa_k, const float* B, long sb_k, long sb_n, const float* bias,
+                        float* C, long ldc, int M, int N, int K, int accumulate, void* stream);
+
+/* y = act(z) and dz += dy * act'(z); act: OTTER_EPI_ACT_* (nn.GELU of transformer.py:75-79 / timm Mlp, nn.ReLU of models.py:42-66). */
+int otter_act_fwd(const float* z, float* y, long n, int act, void* stream);
+int otter_act_bwd(const float* z, const float* dy, float* dz, long n, int act, void* stream);
+
+/* out[c] (+)= sum_r x[r, c] * (y ? y[r, c] : 1): bias gradients and gradients of parameters broadcast over rows. */
+int otter_col_sum(const float* x, long ldx, const float* y, long ldy, int rows, int cols, float* out, int accumulate, void* stream);
+
+/* nn.LayerNorm backward (transformer.py:62-63,176-178): dx += d loss / d x (dx may be NULL); with dgamma/dbeta
+ * (both or neither) also dgamma += , dbeta += ; stats: workspace of 2*rows floats, required with dgamma.
+ * gamma NULL = no affine. */
+int otter_layernorm_bwd(const float* x, long ldx, const float* gamma, const float* dy, long ldy, float* dx, long lddx,
+                        float* stats, float* dgamma, float* dbeta, int rows, int width, float eps, void* stream);
+
+/* Small multi-head attention, fp32 (F.scaled_dot_product_attention of transformer.py:44-47 with is_causal, and
+ * nn.MultiheadAttention with key_padding_mask of transformer.py:189-191).  Element (b, i, h, e) of q is
+ * q[b*sq_b + i*sq_l + h*head_dim + e]; k and v share strides; sq_b = 0 broadcasts one query set over the batch.
+ * key_mask [B][Lk] bytes (row stride sm_b), non-zero = ignore, or NULL.  Lq, Lk <= 32, head_dim <= 128.
+ * Backward recomputes the probabilities; dq/dk/dv (any may be NULL) are accumulated with the strides given. */
+int otter_small_attn_fwd(const float* q, long sq_b, long sq_l, const float* k, const float* v, long sk_b, long sk_l,
+                         const unsigned char* key_mask, long sm_b, float* out, long so_b, long so_l, int B, int H, int Lq,
+                         int Lk, int head_dim, int causal, void* stream);
+int otter_small_attn_bwd(const float* q, long sq_b, long sq_l, const float* k, const float* v, long sk_b, long sk_l,
+                         const unsigned char* key_mask, long sm_b, const float* dout, long so_b, long so_l,
+                         float* dq, long sdq_b, long sdq_l, float* dk, float* dv, int B, int H, int Lq, int Lk,
+                         int head_dim, int causal, void* stream);
+
+/* loss = F.l1_loss / F.mse_loss(pred, gt) (otter.py:378-382), mean over n elements, written to *loss (device);
+ * dpred (may be NULL) = grad_scale * d loss / d pred. */
+int otter_loss_fwd_bwd(const float* pred, const float* gt, long n, int mse, float grad_scale, float* loss, float* dpred, void* stream);
+
+/* out2[0] = sum of squares of the finite elements of x, out2[1] = number of non-finite elements
+ * (get_grad_norm_ and the GradScaler inf check, misc.py:336-343,351-366).  workspace: otter_grad_stats_workspace_floats(). */
+long otter_grad_stats_workspace_floats(void);
+int otter_grad_stats(const float* x, long n, float* workspace, float* out2, void* stream);
+
+/* torch.optim.AdamW step on flat fp32 buffers (train.py:170-171): grad is multiplied by inv_scale first
+ * (GradScaler.unscale_); skip_flag (device float, may be NULL): non-zero skips the update (GradScaler.step). */
+int otter_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float inv_scale, const float* skip_flag, void* stream);
+int otter_scale_inplace(float* x, long n, float alpha, void* stream);
+
+/* d loss / d temperature of TextAwareVisualExtraction (models.py:17-18,31-32): partial[m*cams + c] = contribution of
+ * unit (m, c); operands as otter_text_aware_pool_fwd except pos: fp32 [cams][P][D] (the pos_emb buffers) and
+ * grad_out: fp32 [cams][n_obs][K][D]. */
+int otter_text_aware_pool_temperature_grad(int dtype, const void* patches, long unit_stride, const float* text, const float* pos,
+                                           const float* temperature, const float* grad_out, float* partial, int n_obs, int cams,
+                                           int P, int D, int K, int t_rep, void* stream);
 
 #ifdef __cplusplus
 }

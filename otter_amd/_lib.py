@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
@@ -50,6 +50,19 @@ _SIGNATURES = {
     "otter_repeat_rows": [_P, _L, _P, _L, _I, _I, _I, _P],
     "otter_add_pe": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "otter_window_append": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    # training step
+    "otter_sgemm_strided": [_P, _L, _L, _P, _L, _L, _P, _P, _L, _I, _I, _I, _I, _P],
+    "otter_act_fwd": [_P, _P, _L, _I, _P],
+    "otter_act_bwd": [_P, _P, _P, _L, _I, _P],
+    "otter_col_sum": [_P, _L, _P, _L, _I, _I, _P, _I, _P],
+    "otter_layernorm_bwd": [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _F, _P],
+    "otter_small_attn_fwd": [_P, _L, _L, _P, _P, _L, _L, _P, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P],
+    "otter_small_attn_bwd": [_P, _L, _L, _P, _P, _L, _L, _P, _L, _P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "otter_loss_fwd_bwd": [_P, _P, _L, _I, _F, _P, _P, _P],
+    "otter_grad_stats": [_P, _L, _P, _P, _P],
+    "otter_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P],
+    "otter_scale_inplace": [_P, _L, _F, _P],
+    "otter_text_aware_pool_temperature_grad": [_I, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
 
 _lib = None
@@ -76,6 +89,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.otter_grad_stats_workspace_floats.restype = c_long
+    lib.otter_grad_stats_workspace_floats.argtypes = []
     _lib = lib
     return lib
 
@@ -88,4 +103,4 @@ def call(name: str, *args) -> None:
 
 
 def exported_names():
-    return sorted(list(_SIGNATURES) + ["otter_last_error", "otter_hip_abi_version"])
+    return sorted(list(_SIGNATURES) + ["otter_last_error", "otter_hip_abi_version", "otter_grad_stats_workspace_floats"])

@@ -229,14 +229,14 @@ class OtterDevice:
 
     def __init__(self, sd: Dict[str, Tensor], arch: ClipArch, *, first_k: int, pooling_heads: int, transformer_heads: int,
                  num_cameras: int, seq_length: int, action_horizon: int, action_dim: int, pool_true_text: bool, device,
-                 clip_dtype=torch.float16):
+                 clip_dtype=torch.float16, clip: Optional["ClipDevice"] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ops.OtterHipError(f"OtterDevice needs a HIP device, got {device!r}; there is no CPU path")
         self.cams, self.first_k = num_cameras, first_k
         self.seq_length, self.horizon, self.action_dim = seq_length, action_horizon, action_dim
         self.pool_true_text = pool_true_text
-        self.clip = ClipDevice(sd, arch, first_k, self.device, clip_dtype)
+        self.clip = clip if clip is not None else ClipDevice(sd, arch, first_k, self.device, clip_dtype)
         sdd = {k: v.detach().to(self.device) for k, v in sd.items() if not k.startswith("clip_model.")}
         self.text_pool = PoolingWeights(sdd, "text_pooling.", pooling_heads)
         self.vis_pool = [PoolingWeights(sdd, f"vision_poolings.{c}.", pooling_heads) for c in range(num_cameras)]

@@ -371,3 +371,208 @@ def window_append(src: Tensor, fresh: Tensor, dst: Tensor, lens_in: Tensor, lens
         if not t.is_contiguous():
             raise ValueError("window_append: operands must be contiguous")
     _lib.call("otter_window_append", _ptr(src), _ptr(fresh), _ptr(dst), _ptr(lens_in), _ptr(lens_out), b, s, dim, _stream())
+
+
+# ------------------------------------------------------------------------------------------------------ training step
+def _f32_2d(t: Tensor, name: str):
+    _chk(t, torch.float32, name, 2)
+    return _rows_view(t, name)
+
+
+def sgemm(a: Tensor, b: Tensor, out: Tensor, *, trans_a: bool = False, trans_b: bool = False, bias: Optional[Tensor] = None,
+          accumulate: bool = False) -> Tensor:
+    """out (+)= op(a) @ op(b) (+ bias), fp32, 2-D row-major views with arbitrary row strides (no packing)."""
+    ra, ca, lda = _f32_2d(a, "sgemm.a")
+    rb, cb, ldb = _f32_2d(b, "sgemm.b")
+    m, k = (ca, ra) if trans_a else (ra, ca)
+    kb, n = (cb, rb) if trans_b else (rb, cb)
+    ro, co, ldc = _f32_2d(out, "sgemm.out")
+    if k != kb or ro != m or co != n:
+        raise ValueError(f"sgemm: op(a) is ({m},{k}), op(b) is ({kb},{n}), out is ({ro},{co})")
+    if bias is not None:
+        _chk(bias, torch.float32, "sgemm.bias", 1)
+        if bias.numel() != n:
+            raise ValueError("sgemm: bias length mismatch")
+    sam, sak = (1, lda) if trans_a else (lda, 1)
+    sbk, sbn = (1, ldb) if trans_b else (ldb, 1)
+    _lib.call("otter_sgemm_strided", _ptr(a), sam, sak, _ptr(b), sbk, sbn, _ptr(bias), _ptr(out), ldc, m, n, k, int(accumulate), _stream())
+    return out
+
+
+def act_fwd(z: Tensor, act: int) -> Tensor:
+    _chk(z, torch.float32, "act.z")
+    if not z.is_contiguous():
+        raise ValueError("act_fwd: contiguous input expected")
+    y = torch.empty_like(z)
+    _lib.call("otter_act_fwd", _ptr(z), _ptr(y), z.numel(), act, _stream())
+    return y
+
+
+def act_bwd(z: Tensor, dy: Tensor, dz: Tensor, act: int) -> None:
+    for t, nm in ((z, "z"), (dy, "dy"), (dz, "dz")):
+        _chk(t, torch.float32, "act_bwd." + nm)
+        if not t.is_contiguous() or t.numel() != z.numel():
+            raise ValueError("act_bwd: contiguous operands of equal size expected")
+    _lib.call("otter_act_bwd", _ptr(z), _ptr(dy), _ptr(dz), z.numel(), act, _stream())
+
+
+def col_sum(x: Tensor, out: Tensor, y: Optional[Tensor] = None, accumulate: bool = True) -> Tensor:
+    """out[c] (+)= sum_r x[r, c] * (y[r, c] if y is given else 1)."""
+    r, c, ldx = _f32_2d(x, "col_sum.x")
+    ldy = 0
+    if y is not None:
+        ry, cy, ldy = _f32_2d(y, "col_sum.y")
+        if (ry, cy) != (r, c):
+            raise ValueError("col_sum: y shape mismatch")
+    _chk(out, torch.float32, "col_sum.out")
+    if out.numel() != c or not out.is_contiguous():
+        raise ValueError("col_sum: out must be contiguous with one element per column")
+    _lib.call("otter_col_sum", _ptr(x), ldx, _ptr(y), ldy, r, c, _ptr(out), int(accumulate), _stream())
+    return out
+
+
+def add_inplace(dst: Tensor, src: Tensor) -> Tensor:
+    """dst += src (contiguous fp32 of equal size)."""
+    if not (dst.is_contiguous() and src.is_contiguous()) or dst.numel() != src.numel():
+        raise ValueError("add_inplace: contiguous operands of equal size expected")
+    return col_sum(src.view(1, -1), dst.view(-1), accumulate=True)
+
+
+def layernorm_bwd(x: Tensor, gamma: Optional[Tensor], dy: Tensor, dx: Optional[Tensor], dgamma: Optional[Tensor] = None,
+                  dbeta: Optional[Tensor] = None, eps: float = 1e-5) -> None:
+    rows, width, ldx = _f32_2d(x, "ln_bwd.x")
+    r2, w2, ldy = _f32_2d(dy, "ln_bwd.dy")
+    if (r2, w2) != (rows, width):
+        raise ValueError("layernorm_bwd: dy shape mismatch")
+    lddx = 0
+    if dx is not None:
+        r3, w3, lddx = _f32_2d(dx, "ln_bwd.dx")
+        if (r3, w3) != (rows, width):
+            raise ValueError("layernorm_bwd: dx shape mismatch")
+    stats = torch.empty(2 * max(rows, 1), dtype=torch.float32, device=x.device) if dgamma is not None else None
+    for t in (gamma, dgamma, dbeta):
+        if t is not None:
+            _chk(t, torch.float32, "ln_bwd.param", 1)
+            if t.numel() != width or not t.is_contiguous():
+                raise ValueError("layernorm_bwd: parameter length mismatch")
+    _lib.call("otter_layernorm_bwd", _ptr(x), ldx, _ptr(gamma), _ptr(dy), ldy, _ptr(dx), lddx, _ptr(stats), _ptr(dgamma), _ptr(dbeta),
+              rows, width, eps, _stream())
+
+
+def _attn_strides(t: Tensor, name: str, heads: int, hd: int):
+    """t: (B, L, >=heads*hd) view with contiguous last dim -> (batch stride, row stride)."""
+    _chk(t, torch.float32, name, 3)
+    if t.shape[2] != heads * hd:
+        raise ValueError(f"{name}: last dim {t.shape[2]} != heads*head_dim {heads * hd}")
+    return t.stride(0), t.stride(1)
+
+
+def small_attn_fwd(q: Tensor, k: Tensor, v: Tensor, heads: int, causal: bool, key_mask: Optional[Tensor] = None,
+                   broadcast_q: bool = False) -> Tensor:
+    """q (B or 1, Lq, d), k/v (B, Lk, d) fp32 views (same strides for k and v) -> (B, Lq, d)."""
+    b, lk, d = k.shape
+    hd = d // heads
+    lq = q.shape[1]
+    sqb, sql = _attn_strides(q, "attn.q", heads, hd)
+    skb, skl = _attn_strides(k, "attn.k", heads, hd)
+    if _attn_strides(v, "attn.v", heads, hd) != (skb, skl):
+        raise ValueError("small_attn: k and v must share strides")
+    if broadcast_q:
+        sqb = 0
+    elif q.shape[0] != b:
+        raise ValueError("small_attn: batch mismatch")
+    smb = 0
+    if key_mask is not None:
+        _chk(key_mask, torch.uint8, "attn.mask", 2)
+        smb = key_mask.stride(0)
+    out = torch.empty(b, lq, d, dtype=torch.float32, device=k.device)
+    _lib.call("otter_small_attn_fwd", _ptr(q), sqb, sql, _ptr(k), _ptr(v), skb, skl, _ptr(key_mask), smb, _ptr(out), lq * d, d,
+              b, heads, lq, lk, hd, int(causal), _stream())
+    return out
+
+
+def small_attn_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, dq: Optional[Tensor], dk: Optional[Tensor], dv: Optional[Tensor],
+                   heads: int, causal: bool, key_mask: Optional[Tensor] = None, broadcast_q: bool = False) -> None:
+    """Accumulates into dq (B, Lq, d) and dk / dv (views with the strides of k)."""
+    b, lk, d = k.shape
+    hd = d // heads
+    lq = q.shape[1]
+    sqb, sql = _attn_strides(q, "attn.q", heads, hd)
+    skb, skl = _attn_strides(k, "attn.k", heads, hd)
+    if broadcast_q:
+        sqb = 0
+    _chk(dout, torch.float32, "attn.dout", 3)
+    if tuple(dout.shape) != (b, lq, d) or not dout.is_contiguous():
+        raise ValueError("small_attn_bwd: dout must be contiguous (B, Lq, d)")
+    sdqb = sdql = 0
+    if dq is not None:
+        sdqb, sdql = _attn_strides(dq, "attn.dq", heads, hd)
+        if dq.shape[0] != b:
+            raise ValueError("small_attn_bwd: dq must have one slab per batch element")
+    for t, nm in ((dk, "dk"), (dv, "dv")):
+        if t is not None and _attn_strides(t, "attn." + nm, heads, hd) != (skb, skl):
+            raise ValueError(f"small_attn_bwd: {nm} must share the strides of k")
+    smb = key_mask.stride(0) if key_mask is not None else 0
+    _lib.call("otter_small_attn_bwd", _ptr(q), sqb, sql, _ptr(k), _ptr(v), skb, skl, _ptr(key_mask), smb, _ptr(dout), lq * d, d,
+              _ptr(dq), sdqb, sdql, _ptr(dk), _ptr(dv), b, heads, lq, lk, hd, int(causal), _stream())
+
+
+def loss_fwd_bwd(pred: Tensor, gt: Tensor, mse: bool, grad_scale: float, want_grad: bool = True):
+    """-> (loss (1,) device tensor, dpred or None)."""
+    _chk(pred, torch.float32, "loss.pred")
+    _chk(gt, torch.float32, "loss.gt")
+    if pred.numel() != gt.numel() or not pred.is_contiguous() or not gt.is_contiguous():
+        raise ValueError("loss: pred and gt must be contiguous with the same number of elements")
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    _lib.call("otter_loss_fwd_bwd", _ptr(pred), _ptr(gt), pred.numel(), int(mse), float(grad_scale), _ptr(loss), _ptr(dpred), _stream())
+    return loss, dpred
+
+
+def grad_stats(x: Tensor, workspace: Optional[Tensor] = None) -> Tensor:
+    """-> device tensor [sum of squares of finite elements, number of non-finite elements]."""
+    _chk(x, torch.float32, "grad_stats.x", 1)
+    n_ws = _lib.load().otter_grad_stats_workspace_floats()
+    if workspace is None:
+        workspace = torch.empty(n_ws, dtype=torch.float32, device=x.device)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    _lib.call("otter_grad_stats", _ptr(x), x.numel(), _ptr(workspace), _ptr(out), _stream())
+    return out
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float,
+               step: int, inv_scale: float = 1.0, skip_flag: Optional[Tensor] = None) -> None:
+    for t in (p, g, m, v):
+        _chk(t, torch.float32, "adamw", 1)
+        if not t.is_contiguous() or t.numel() != p.numel():
+            raise ValueError("adamw_step: flat contiguous buffers of equal length expected")
+    _lib.call("otter_adamw_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+              float(weight_decay), int(step), float(inv_scale), _ptr(skip_flag), _stream())
+
+
+def scale_inplace(x: Tensor, alpha: float) -> None:
+    _chk(x, torch.float32, "scale.x")
+    if not x.is_contiguous():
+        raise ValueError("scale_inplace: contiguous tensor expected")
+    _lib.call("otter_scale_inplace", _ptr(x), x.numel(), float(alpha), _stream())
+
+
+def text_aware_pool_temperature_grad(patches: Tensor, text: Tensor, pos: Tensor, temperature: Tensor, grad_out: Tensor, n_obs: int,
+                                     cams: int, t_rep: int, n_patches: Optional[int] = None) -> Tensor:
+    """-> fp32 (n_obs, cams): every unit's contribution to d loss / d temperature[cam]."""
+    dt = _dt(patches.dtype, "tave_grad.patches", False)
+    units, rows, d = patches.shape
+    p = n_patches if n_patches is not None else rows
+    k = text.shape[1]
+    _chk(pos, torch.float32, "tave_grad.pos", 3)
+    _chk(grad_out, torch.float32, "tave_grad.grad_out", 4)
+    if tuple(pos.shape) != (cams, p, d) or tuple(grad_out.shape) != (cams, n_obs, k, d) or units != n_obs * cams:
+        raise ValueError("tave_grad: shape mismatch")
+    for t in (patches, text, pos, temperature, grad_out):
+        if not t.is_contiguous():
+            raise ValueError("tave_grad: operands must be contiguous")
+    partial = torch.empty(n_obs, cams, dtype=torch.float32, device=patches.device)
+    base = ctypes.c_void_p(patches.data_ptr() + (rows - p) * d * 2)
+    _lib.call("otter_text_aware_pool_temperature_grad", dt, base, rows * d, _ptr(text), _ptr(pos), _ptr(temperature), _ptr(grad_out),
+              _ptr(partial), n_obs, cams, p, d, k, t_rep, _stream())
+    return partial

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import ops
 from .config import ModelConfig, SharedConfig, clip_arch
-from .device_model import OtterDevice
+from .device_model import ClipDevice, OtterDevice
 from .engine import BatchedRollout
 from .params import Node, attach, otter_specs
 from .tokenizer import EOT_TOKEN, SOT_TOKEN, tokenize
@@ -66,36 +66,58 @@ class OTTER(nn.Module):
         self.clip_compute_dtype = torch.float16
         self._dev: Optional[OtterDevice] = None
         self._dev_key = None
+        self._clip_dev: Optional[ClipDevice] = None
+        self._clip_key = None
+        self._tail = None
         self._rollout: Optional[BatchedRollout] = None
         self.cache_size = 0
 
     # ------------------------------------------------------------------ device state
     def _apply(self, fn, *a, **k):
         self._dev = None
+        self._clip_dev = None
+        self._tail = None
         self._rollout = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._dev = None
+        self._clip_dev = None
         self._rollout = None
         return super().load_state_dict(*a, **k)
 
-    def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters() if p.requires_grad)
+    def _weights_key(self, trainable: bool):
+        return tuple((p.data_ptr(), p._version) for n, p in self.named_parameters() if n.startswith("clip_model.") != trainable)
 
-    def device_model(self) -> OtterDevice:
-        """Packed device weights, rebuilt when the module moved or a trainable parameter changed."""
+    def _device(self) -> torch.device:
         device = self.input_projection.weight.device
         if device.type != "cuda":
             raise ops.OtterHipError(
                 f"OTTER is on {device}; move it to the GPU first (model.to('cuda')). The hot path has no CPU implementation.")
-        key = self._weights_key()
+        return device
+
+    def clip_device(self) -> ClipDevice:
+        """Packed weights of the frozen CLIP towers (rebuilt only when a CLIP tensor or the operand type changes)."""
+        device = self._device()
+        key = (self._weights_key(False), self.clip_compute_dtype, device)
+        if self._clip_dev is None or self._clip_key != key:
+            sd = {k: v for k, v in self.state_dict().items() if k.startswith("clip_model.")}
+            self._clip_dev = ClipDevice(sd, self.clip_arch, self.first_k_tokens, device, self.clip_compute_dtype)
+            self._clip_key = key
+            self._dev = None
+        return self._clip_dev
+
+    def device_model(self) -> OtterDevice:
+        """Packed device weights, rebuilt when the module moved or a trainable parameter changed."""
+        device = self._device()
+        clip = self.clip_device()
+        key = self._weights_key(True)
         if self._dev is None or self._dev_key != key:
             self._dev = OtterDevice(
                 dict(self.state_dict()), self.clip_arch, first_k=self.first_k_tokens, pooling_heads=self.pooling_heads,
                 transformer_heads=self.transformer_heads, num_cameras=len(self.camera_keys), seq_length=self.seq_length,
                 action_horizon=self.action_horizon, action_dim=self.action_dim, pool_true_text=self.pool_true_text, device=device,
-                clip_dtype=self.clip_compute_dtype)
+                clip_dtype=self.clip_compute_dtype, clip=clip)
             self._dev_key = key
             self._rollout = None
         return self._dev
@@ -209,11 +231,25 @@ class OTTER(nn.Module):
             text = tokenize(text)
         text_mask = create_text_mask(text, self.sot_token, self.eot_token, self.first_k_tokens) if self.pool_true_text else None
         # uint8 images are normalised on the device inside the patch-extraction kernel (vision_tf.py:35-45)
-        actions = self.forward_actions(images, text, proprio, text_mask)
         if gt_actions is None:
-            return actions
-        gt = gt_actions.to(actions.device, actions.dtype)
-        return torch.nn.functional.mse_loss(actions, gt) if self.use_mse else torch.nn.functional.l1_loss(actions, gt)
+            return self.forward_actions(images, text, proprio, text_mask)
+        return self.loss(images, text, proprio, gt_actions, text_mask)
+
+    def loss(self, images: Tensor, text: Tensor, proprio: Tensor, gt_actions: Tensor, text_mask: Optional[Tensor] = None) -> Tensor:
+        """L1 / MSE loss of the predicted chunks (``otter.py:378-382``) as a scalar tensor.  With autograd enabled it is a
+        differentiable function of the trainable parameters (hand-written backward, :mod:`otter_amd.train`)."""
+        from .train import TailLoss, TrainableTail
+        if self._tail is None:
+            self._tail = TrainableTail(self)
+        tail = self._tail
+        device = self._device()
+        ids = text.detach().to("cpu", torch.int32).view(-1, text.shape[-1])
+        imgs = images.to(device)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in tail.params.values()):
+            names = list(tail.params)
+            return TailLoss.apply(tail, imgs, ids, proprio, gt_actions, text_mask, names, *[tail.params[n] for n in names])
+        with torch.no_grad():
+            return tail.forward_backward(imgs, ids, proprio, gt_actions, text_mask, None).view(())
 
     def __repr__(self):
         n = lambda it: sum(p.numel() for p in it)          # noqa: E731

@@ -1,0 +1,255 @@
+"""Training step on the GPU: every hand-written backward kernel against torch autograd on the CPU (fp32), then the
+whole trainable tail against (a) the gradient norms the reference's own OTTER class produced (fixtures) and
+(b) autograd through the CPU oracle for every trainable tensor."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+from oracle import otter_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from otter_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _randn(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("m,n,k", [(192, 768, 768), (5, 120, 1536), (70, 33, 17), (1, 64, 10), (300, 2304, 704)])
+def test_sgemm_all_transposes(dev, m, n, k):
+    from otter_amd import ops
+    a, b, bias = _randn(1, m, k), _randn(2, n, k) / math.sqrt(k), _randn(3, n)
+    out = torch.empty(m, n, device=dev)
+    ops.sgemm(a.to(dev), b.to(dev), out, trans_b=True, bias=bias.to(dev))                 # forward: x W^T + b
+    ref = a.double() @ b.double().t() + bias.double()
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    dy = _randn(4, m, n)
+    dx = torch.full((m, k), 0.5, device=dev)
+    ops.sgemm(dy.to(dev), b.to(dev), dx, accumulate=True)                                  # input gradient, accumulated
+    torch.testing.assert_close(dx.cpu().double(), 0.5 + dy.double() @ b.double(), rtol=1e-5, atol=1e-5)
+    dw = torch.zeros(n, k, device=dev)
+    ops.sgemm(dy.to(dev), a.to(dev), dw, trans_a=True, accumulate=True)                     # weight gradient dy^T x
+    torch.testing.assert_close(dw.cpu().double(), dy.double().t() @ a.double(), rtol=1e-5, atol=1e-4)   # fp32 sums of up to 300 O(1) products
+    # strided views: a column slice as output, a wider buffer as input
+    wide = torch.zeros(m, n + 16, device=dev)
+    ops.sgemm(a.to(dev), b.to(dev), wide[:, 8:8 + n], trans_b=True)
+    torch.testing.assert_close(wide[:, 8:8 + n].cpu().double(), a.double() @ b.double().t(), rtol=1e-5, atol=1e-5)
+    assert torch.all(wide[:, :8] == 0) and torch.all(wide[:, 8 + n:] == 0)
+
+
+@pytest.mark.parametrize("act", ["gelu", "relu", "quickgelu"])
+def test_activation_backward(dev, act):
+    from otter_amd import ops
+    code = {"gelu": ops.ACT_GELU, "relu": ops.ACT_RELU, "quickgelu": ops.ACT_QUICKGELU}[act]
+    z = (_randn(5, 37, 129) * 2).requires_grad_(True)
+    fn = {"gelu": torch.nn.functional.gelu, "relu": torch.relu, "quickgelu": lambda x: x * torch.sigmoid(1.702 * x)}[act]
+    y = fn(z)
+    dy = _randn(6, 37, 129)
+    y.backward(dy)
+    got_y = ops.act_fwd(z.detach().to(dev), code)
+    torch.testing.assert_close(got_y.cpu(), y.detach(), rtol=1e-5, atol=1e-6)
+    dz = torch.ones(37, 129, device=dev)
+    ops.act_bwd(z.detach().to(dev), dy.to(dev), dz, code)
+    torch.testing.assert_close(dz.cpu(), 1 + z.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,width", [(192, 768), (7, 64), (61, 32), (1000, 128)])
+def test_layernorm_backward(dev, rows, width):
+    from otter_amd import ops
+    x = (_randn(7, rows, width) * 2 + 0.3).requires_grad_(True)
+    g = (_randn(8, width) * 0.2 + 1).requires_grad_(True)
+    b = _randn(9, width).requires_grad_(True)
+    dy = _randn(10, rows, width)
+    torch.nn.functional.layer_norm(x, (width,), g, b, 1e-5).backward(dy)
+    dx, dg, db = torch.zeros(rows, width, device=dev), torch.zeros(width, device=dev), torch.zeros(width, device=dev)
+    ops.layernorm_bwd(x.detach().to(dev), g.detach().to(dev), dy.to(dev), dx, dg, db)
+    torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dg.cpu(), g.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("b,lq,lk,heads,hd,causal,masked,bq", [
+    (6, 12, 12, 8, 96, True, False, False),      # policy transformer
+    (5, 4, 15, 8, 8, False, False, True),         # vision readout, shared queries
+    (5, 4, 15, 8, 4, False, True, False),         # text readout with key padding mask
+    (3, 32, 32, 2, 64, True, False, False),       # longest window
+])
+def test_small_attention_fwd_bwd(dev, b, lq, lk, heads, hd, causal, masked, bq):
+    from otter_amd import ops
+    d = heads * hd
+    q = _randn(11, 1 if bq else b, lq, d).requires_grad_(True)
+    kv = _randn(12, b, lk, 2 * d).requires_grad_(True)
+    mask = None
+    if masked:
+        mask = torch.zeros(b, lk, dtype=torch.bool)
+        mask[:, -3:] = True
+        mask[1, 0] = True
+    qq = q.expand(b, lq, d).view(b, lq, heads, hd).transpose(1, 2)
+    kk = kv[..., :d].view(b, lk, heads, hd).transpose(1, 2)
+    vv = kv[..., d:].view(b, lk, heads, hd).transpose(1, 2)
+    s = (qq @ kk.transpose(-1, -2)) / math.sqrt(hd)
+    if causal:
+        s = s + torch.full((lq, lk), float("-inf")).triu(1)
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    o = (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(b, lq, d)
+    do = _randn(13, b, lq, d)
+    o.backward(do)
+    qd, kvd = q.detach().to(dev), kv.detach().to(dev)
+    m8 = None if mask is None else mask.to(torch.uint8).to(dev)
+    got = ops.small_attn_fwd(qd, kvd[..., :d], kvd[..., d:], heads, causal, m8, broadcast_q=bq)
+    torch.testing.assert_close(got.cpu(), o.detach(), rtol=1e-4, atol=1e-5)
+    dq = torch.zeros(b, lq, d, device=dev)
+    dkv = torch.zeros(b, lk, 2 * d, device=dev)
+    ops.small_attn_bwd(qd, kvd[..., :d], kvd[..., d:], do.to(dev), dq, dkv[..., :d], dkv[..., d:], heads, causal, m8, broadcast_q=bq)
+    ref_dq = q.grad if not bq else None
+    if bq:
+        torch.testing.assert_close(dq.sum(0, keepdim=True).cpu(), q.grad, rtol=1e-4, atol=1e-4)
+    else:
+        torch.testing.assert_close(dq.cpu(), ref_dq, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dkv.cpu(), kv.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("mse", [False, True])
+def test_loss_and_stats(dev, mse):
+    from otter_amd import ops
+    pred = _randn(14, 36, 120).requires_grad_(True)
+    gt = _randn(15, 36, 120)
+    ref = torch.nn.functional.mse_loss(pred, gt) if mse else torch.nn.functional.l1_loss(pred, gt)
+    (ref * 3.0).backward()
+    loss, dp = ops.loss_fwd_bwd(pred.detach().to(dev), gt.to(dev), mse, 3.0)
+    assert abs(loss.item() - ref.item()) <= 1e-6 * max(1.0, abs(ref.item()))
+    torch.testing.assert_close(dp.cpu(), pred.grad, rtol=1e-5, atol=1e-8)
+    x = _randn(16, 100003)
+    st = ops.grad_stats(x.to(dev)).cpu()
+    exact = float((x.double() ** 2).sum())
+    assert abs(st[0].item() - exact) <= 1e-6 * exact and st[1].item() == 0          # fp32 two-stage sum
+    x[17] = float("inf")
+    x[9999] = float("nan")
+    assert ops.grad_stats(x.to(dev)).cpu()[1].item() == 2
+
+
+def test_adamw_matches_torch(dev):
+    from otter_amd import ops
+    p0 = _randn(17, 5000)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=3e-4, weight_decay=0.01)
+    p, m, v = p0.clone().to(dev), torch.zeros(5000, device=dev), torch.zeros(5000, device=dev)
+    for step in range(1, 6):
+        g = _randn(100 + step, 5000)
+        ref_p.grad = g.clone()
+        opt.step()
+        ops.adamw_step(p, (g * 8.0).to(dev), m, v, lr=3e-4, weight_decay=0.01, step=step, inv_scale=1.0 / 8.0)
+    torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=1e-5, atol=1e-6)
+    flag = torch.ones(1, device=dev)
+    before = p.clone()
+    ops.adamw_step(p, torch.ones(5000, device=dev), m, v, lr=3e-4, weight_decay=0.01, step=6, skip_flag=flag)
+    assert torch.equal(p, before)                                    # non-finite gradients: the step is skipped
+
+
+def test_temperature_gradient(dev):
+    from otter_amd import ops
+    m, cams, p, d, k = 3, 2, 64, 128, 15
+    patches = _randn(18, m * cams, p + 1, d).half()
+    text = _randn(19, m, k, d)
+    pos = _randn(20, cams, p, d) * 0.5
+    temp = torch.tensor([0.07, 0.3], requires_grad=True)
+    gout = _randn(21, cams, m, k, d)
+    x = patches[:, 1:].float().view(m, cams, p, d)
+    xh = x / x.norm(dim=-1, keepdim=True)
+    th = text / text.norm(dim=-1, keepdim=True)
+    total = 0
+    for c in range(cams):
+        out = R.text_aware_visual_extraction(xh[:, c], th, temp[c], pos[c])
+        total = total + (out * gout[c]).sum()
+    total.backward()
+    part = ops.text_aware_pool_temperature_grad(patches.to(dev), text.to(dev), pos.to(dev), temp.detach().to(dev), gout.to(dev), m, cams, 1, n_patches=p)
+    got = part.sum(0).cpu()
+    torch.testing.assert_close(got, temp.grad, rtol=2e-3, atol=1e-4)
+    # outside the clamp range the gradient is zero
+    t2 = torch.tensor([150.0, -1.0])
+    part = ops.text_aware_pool_temperature_grad(patches.to(dev), text.to(dev), pos.to(dev), t2.to(dev), gout.to(dev), m, cams, 1, n_patches=p)
+    assert torch.all(part == 0)
+
+
+def _model(mc, sc, seed, dev):
+    from otter_amd.otter import OTTER
+    from otter_amd.params import otter_specs, random_state_dict
+    sd = random_state_dict(otter_specs(mc, sc), seed=seed)
+    model = OTTER(mc, sc)
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev), sd
+
+
+@pytest.mark.parametrize("case", GI.E2E_CASES, ids=lambda c: c["name"])
+def test_tail_gradients_match_reference_and_oracle(dev, golden, case):
+    g = golden("otter_e2e")
+    n = case["name"]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    model.train()
+    images, text, proprio, gt = GI.e2e_inputs(case)
+    loss = model(images.to(dev), text, proprio.to(dev), gt.to(dev))
+    assert loss.requires_grad
+    loss.backward()
+    assert abs(loss.item() - float(g[n + "__loss"])) <= 1e-3
+    # (a) gradient norms recorded from the reference's own OTTER class (tests/test_dummy_model.py:55-66 checks the same four)
+    got = [model.visual_extraction[0].temperature.grad.norm().item(), model.vision_poolings[0].query.grad.norm().item(),
+           model.text_pooling.query.grad.norm().item(), list(model.action_head.parameters())[0].grad.norm().item()]
+    ref = g[n + "__gradnorms"]
+    print(n, "grad norms", got, "reference", ref.tolist())
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=1e-6)
+    # (b) every trainable tensor against autograd through the fp32 CPU oracle
+    sdg = {k: (v.clone().requires_grad_(True) if (not k.startswith("clip_model.") and v.is_floating_point()
+                                                   and k in dict(model.named_parameters())) else v) for k, v in sd.items()}
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length, num_cameras=len(sc.camera_keys),
+                  pool_true_text=mc.pool_true_text, use_mse=sc.mse_loss)
+    ref_loss = R.forward(images, text, proprio, sdg, dims, gt)
+    ref_loss.backward()
+    worst = 0.0
+    checked = 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        rg = sdg[name].grad
+        assert rg is not None, name
+        err, ref_norm = (p.grad.cpu() - rg).norm().item(), rg.norm().item()
+        # 2 % of the tensor's gradient norm (the towers feed fp16-rounded features into the tail) plus an absolute floor
+        # for gradients that are zero in exact arithmetic (key biases: softmax is shift invariant)
+        assert err <= 2e-2 * ref_norm + 1e-6, f"{name}: gradient error {err:.3e} vs norm {ref_norm:.3e}"
+        if ref_norm > 1e-5:
+            worst = max(worst, err / ref_norm)
+        checked += 1
+    print(f"{n}: {checked} trainable tensors, worst relative gradient error {worst:.2e}")
+
+
+def test_loss_scaling_and_accumulation(dev):
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, _ = _model(mc, sc, case["seed"], dev)
+    model.train()
+    images, text, proprio, gt = GI.e2e_inputs(case)
+    model(images.to(dev), text, proprio.to(dev), gt.to(dev)).backward()
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
+    model.zero_grad()
+    (model(images.to(dev), text, proprio.to(dev), gt.to(dev)) * 4.0).backward()       # what GradScaler.scale(loss).backward() does
+    (model(images.to(dev), text, proprio.to(dev), gt.to(dev)) * 4.0).backward()       # second micro-batch accumulates
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            torch.testing.assert_close(p.grad, 8.0 * g1[n], rtol=1e-4, atol=1e-7)
+    with torch.no_grad():
+        plain = model(images.to(dev), text, proprio.to(dev), gt.to(dev))
+    assert not plain.requires_grad

@@ -1,0 +1,195 @@
+"""Data-parallel training step (``script/train.py:100-171``, ``otter/util/engine.py:15-66``, ``otter/util/misc.py``).
+
+What the reference assembles from torch pieces -- ``add_weight_decay`` parameter groups, ``torch.optim.AdamW``,
+``torch.amp.GradScaler`` inside ``NativeScalerWithGradNormCount``, the cosine-with-warmup ``LambdaLR`` and
+``DistributedDataParallel`` -- is one object here, laid out for the device:
+
+* every trainable tensor lives in ONE flat fp32 buffer (no-decay group first, decay group second; the module's
+  parameters are views into it), with flat gradient / first-moment / second-moment buffers beside it;
+* the hand-written backward (:mod:`otter_amd.train`) accumulates straight into the flat gradient buffer;
+* ranks exchange gradients with a bucketed all-reduce over the flat buffer (RCCL on the GPUs; the SUM is turned
+  into DistributedDataParallel's mean by folding 1/world into the unscale factor);
+* gradient norm + non-finite check are one two-stage reduction, AdamW is one kernel launch per group and skips
+  itself on the device when the check failed (GradScaler semantics without a host round trip before the update).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+Tensor = torch.Tensor
+
+
+# ------------------------------------------------------------------------------------------ pure host-side pieces
+def add_weight_decay(model, weight_decay: float = 1e-5, skip_list: Iterable[str] = ()) -> List[dict]:
+    """``otter/util/misc.py:442-454``: 1-D tensors, ``*.bias`` and names in ``skip_list`` get no weight decay.
+    (A 0-d tensor such as the extraction temperature has ``len(shape) == 0`` and therefore DOES decay, as upstream.)"""
+    decay, no_decay = [], []
+    skip = set(skip_list)
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (len(p.shape) == 1 or name.endswith(".bias") or name in skip) else decay).append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+def cosine_with_warmup(step: int, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5) -> float:
+    """Multiplier of the base learning rate at scheduler step ``step`` (``otter/util/lr_sched.py:148-179``)."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
+class LossScale:
+    """``torch.amp.GradScaler`` bookkeeping (defaults: 2**16, x2 after 2000 clean steps, x0.5 on a non-finite gradient)."""
+
+    def __init__(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000, enabled: bool = True):
+        self.scale = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval, self.enabled = growth_factor, backoff_factor, growth_interval, enabled
+        self._good = 0
+
+    def update(self, found_inf: bool) -> None:
+        if not self.enabled:
+            return
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good == self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+
+    def state_dict(self) -> dict:
+        return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self._good}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.scale, self._good = float(sd["scale"]), int(sd["_growth_tracker"])
+
+
+FLAT_ALIGN = 64      # elements
+
+
+def bucket_bounds(n: int, bucket_elems: int) -> List[Tuple[int, int]]:
+    if bucket_elems <= 0:
+        raise ValueError("bucket size must be positive")
+    return [(lo, min(n, lo + bucket_elems)) for lo in range(0, n, bucket_elems)]
+
+
+def allreduce_flat(flat: Tensor, bucket_elems: int = 8 << 20) -> None:
+    """SUM-all-reduce a flat buffer across the default process group in buckets, all in flight together.
+    xGMI is a point-to-point mesh: a few large buckets (default 32 MiB) keep every link busy without paying the
+    per-collective latency hundreds of times."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for lo, hi in bucket_bounds(flat.numel(), bucket_elems)]
+    for w in works:
+        w.wait()
+
+
+def flatten_parameters(groups: List[dict], device=None) -> Tuple[Tensor, List[Tuple[int, int, float]], Dict[int, Tuple[int, int]]]:
+    """Move every parameter of the groups into one flat fp32 buffer (group after group) and re-point ``p.data`` at its
+    slice.  Every tensor starts on a 256-byte boundary (the kernels use 16-byte vector accesses); the padding is zero
+    and stays zero under AdamW.  Returns (flat, [(lo, hi, weight_decay) per group], {id(p): (lo, hi)})."""
+    align = FLAT_ALIGN
+    total = sum(-(-p.numel() // align) * align for g in groups for p in g["params"])
+    first = next((p for g in groups for p in g["params"]), None)
+    if first is None:
+        raise ValueError("no trainable parameters")
+    device = device or first.device
+    flat = torch.zeros(total, dtype=torch.float32, device=device)
+    spans, where, off = [], {}, 0
+    for g in groups:
+        lo = off
+        for p in g["params"]:
+            n = p.numel()
+            flat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            where[id(p)] = (off, off + n)
+            off += -(-n // align) * align
+        spans.append((lo, off, float(g["weight_decay"])))
+    return flat, spans, where
+
+
+# ------------------------------------------------------------------------------------------------------ the trainer
+class Trainer:
+    """One object = optimizer + loss scaler + lr schedule + gradient exchange for an :class:`otter_amd.otter.OTTER`."""
+
+    def __init__(self, model, *, lr: float = 3e-4, weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8,
+                 warmup_steps: int = 0, num_steps: int = 1, accum_iter: int = 1, loss_scaling: bool = True,
+                 bucket_elems: int = 8 << 20):
+        from . import ops
+        from .train import TrainableTail
+        self.ops = ops
+        self.model = model
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        groups = add_weight_decay(model, weight_decay)
+        self.flat_p, self.spans, where = flatten_parameters(groups)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.tail = TrainableTail(model)
+        self.grads = {n: self.flat_g[where[id(p)][0]:where[id(p)][1]].view(p.shape) for n, p in self.tail.params.items()}
+        self.base_lr, self.betas, self.eps = lr, betas, eps
+        self.warmup_steps, self.num_steps, self.accum_iter = warmup_steps, num_steps, max(1, accum_iter)
+        self.scaler = LossScale(enabled=loss_scaling)
+        self.bucket_elems = bucket_elems
+        self.iteration = 0            # data_iter_step of engine.py:44
+        self.opt_steps = 0            # AdamW's step count (bias correction)
+        self._stats_ws = None
+
+    @property
+    def lr(self) -> float:
+        return self.base_lr * cosine_with_warmup(self.iteration, self.warmup_steps, self.num_steps)
+
+    def step(self, images: Tensor, text: Tensor, proprio: Tensor, gt_actions: Tensor) -> dict:
+        """One iteration of ``engine.train`` (forward, backward, and -- every ``accum_iter`` iterations -- gradient exchange,
+        unscale, norm, AdamW, scaler update).  ``text``: (B, 77) token ids.  Returns loss / grad_norm / lr / skipped."""
+        from .otter import create_text_mask
+        ops, model = self.ops, self.model
+        if self.iteration % self.accum_iter == 0:
+            self.flat_g.zero_()
+        mask = create_text_mask(text, model.sot_token, model.eot_token, model.first_k_tokens) if model.pool_true_text else None
+        ids = text.detach().to("cpu", torch.int32).view(-1, text.shape[-1])
+        device = self.flat_p.device
+        loss = self.tail.forward_backward(images.to(device), ids, proprio, gt_actions, mask, self.grads,
+                                          grad_scale=self.scaler.scale / self.accum_iter)
+        out = {"lr": self.lr, "grad_norm": None, "skipped": False}
+        if (self.iteration + 1) % self.accum_iter == 0:
+            allreduce_flat(self.flat_g, self.bucket_elems)
+            if self._stats_ws is None:
+                self._stats_ws = torch.empty(ops._lib.load().otter_grad_stats_workspace_floats(), dtype=torch.float32, device=device)
+            stats = ops.grad_stats(self.flat_g, self._stats_ws)
+            inv = 1.0 / (self.scaler.scale * self.world)          # unscale_ and DistributedDataParallel's gradient mean
+            self.opt_steps += 1
+            for lo, hi, wd in self.spans:
+                ops.adamw_step(self.flat_p[lo:hi], self.flat_g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], lr=self.lr,
+                               betas=self.betas, eps=self.eps, weight_decay=wd, step=self.opt_steps, inv_scale=inv, skip_flag=stats[1:2])
+            sumsq, bad = stats.tolist()                           # the iteration's one device -> host read (with the loss)
+            found_inf = bad != 0
+            if found_inf:
+                self.opt_steps -= 1                               # the kernels skipped the update
+            out["grad_norm"] = float("inf") if found_inf else math.sqrt(sumsq) * inv
+            out["skipped"] = found_inf
+            self.scaler.update(found_inf)
+            model._dev = None                                     # packed inference weights are stale now
+            model._rollout = None
+        out["loss"] = float(loss.item())
+        self.iteration += 1
+        return out
+
+    def state_dict(self) -> dict:
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "opt_steps": self.opt_steps, "iteration": self.iteration,
+                "scaler": self.scaler.state_dict()}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.opt_steps, self.iteration = int(sd["opt_steps"]), int(sd["iteration"])
+        self.scaler.load_state_dict(sd["scaler"])

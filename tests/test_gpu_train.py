@@ -253,3 +253,50 @@ def test_loss_scaling_and_accumulation(dev):
     with torch.no_grad():
         plain = model(images.to(dev), text, proprio.to(dev), gt.to(dev))
     assert not plain.requires_grad
+
+
+def test_trainer_steps_follow_cpu_adamw_training(dev):
+    """Three iterations of the device Trainer against the same loop written with torch autograd + torch.optim.AdamW on
+    the fp32 CPU oracle (parameter groups as add_weight_decay makes them)."""
+    from otter_amd.trainer import Trainer, add_weight_decay
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    model.train()
+    images, text, proprio, gt = GI.e2e_inputs(case)
+    trainer = Trainer(model, lr=3e-4, weight_decay=0.01, warmup_steps=0, num_steps=100)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    decay = [sdg[n] for n in names if not (sdg[n].dim() == 1 or n.endswith(".bias"))]
+    no_decay = [sdg[n] for n in names if (sdg[n].dim() == 1 or n.endswith(".bias"))]
+    opt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.01}], lr=3e-4)
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length, num_cameras=len(sc.camera_keys),
+                  pool_true_text=mc.pool_true_text, use_mse=sc.mse_loss)
+    for it in range(3):
+        out = trainer.step(images.to(dev), text, proprio.to(dev), gt.to(dev))
+        opt.zero_grad()
+        ref_loss = R.forward(images, text, proprio, sdg, dims, gt)
+        ref_loss.backward()
+        ref_norm = math.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in decay + no_decay))
+        opt.step()
+        print(f"iteration {it}: loss {out['loss']:.6f} (cpu {ref_loss.item():.6f}), grad norm {out['grad_norm']:.5f} (cpu {ref_norm:.5f})")
+        assert not out["skipped"]
+        assert abs(out["loss"] - ref_loss.item()) <= 2e-3
+        assert abs(out["grad_norm"] - ref_norm) <= 2e-2 * ref_norm
+    # Adam normalises each element's step to ~lr: elements whose gradient is pure rounding noise (exactly zero in exact
+    # arithmetic) may step in opposite directions, everything else agrees much closer
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            worst = max(worst, (p.detach().cpu() - sdg[n].detach()).abs().max().item())
+    print(f"max parameter difference after 3 iterations: {worst:.2e}")
+    assert worst <= 2 * 3 * 3e-4 + 1e-5
+    # the module's parameters ARE the flat buffer
+    assert model.input_projection.weight.data_ptr() >= trainer.flat_p.data_ptr()
+    # inference after training sees the updated weights
+    model.eval()
+    a = model(images.to(dev), text, proprio.to(dev)).cpu()
+    with torch.no_grad():
+        ref_a = R.forward(images, text, proprio, {k: v.detach() for k, v in sdg.items()}, dims)
+    assert (a - ref_a).abs().max().item() <= 5e-3

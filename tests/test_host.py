@@ -198,3 +198,69 @@ def test_tokenizer_without_vocabulary_fails_loudly(monkeypatch):
     monkeypatch.setattr(tokenizer, "_default", None)
     with pytest.raises(FileNotFoundError):
         tokenizer.tokenize(["pick up the cube"])
+
+
+# ------------------------------------------------------------------------------------------------ training host logic
+def test_weight_decay_groups_follow_the_reference_rule():
+    from otter_amd.config import ModelConfig, SharedConfig
+    from otter_amd.otter import OTTER
+    from otter_amd.trainer import add_weight_decay
+    mc = ModelConfig(clip_model="tiny-test", transformer_dim=128, transformer_layers=2, transformer_heads=2, vision_pooling_output_dim=128,
+                     text_pooling_output_dim=64, proprio_hidden_dim=64, proprio_output_dim=32, pooling_heads=4)
+    model = OTTER(mc, SharedConfig(image_size=112, seq_length=4, action_horizon=4))
+    no_decay, decay = add_weight_decay(model, 0.01)
+    assert no_decay["weight_decay"] == 0.0 and decay["weight_decay"] == 0.01
+    ids_nd, ids_d = {id(p) for p in no_decay["params"]}, {id(p) for p in decay["params"]}
+    named = dict(model.named_parameters())
+    trainable = {id(p) for p in named.values() if p.requires_grad}
+    assert ids_nd | ids_d == trainable and not (ids_nd & ids_d)
+    assert not any(n.startswith("clip_model.") and id(p) in trainable for n, p in named.items())
+    assert id(named["policy.layers.0.pre_ln.weight"]) in ids_nd and id(named["input_projection.bias"]) in ids_nd
+    assert id(named["text_pooling.blocks.0.attention.in_proj_bias"]) in ids_nd          # 1-D
+    assert id(named["policy.layers.0.mlp.0.weight"]) in ids_d and id(named["text_pooling.query"]) in ids_d
+    assert id(named["visual_extraction.0.temperature"]) in ids_d                          # 0-d: len(shape) != 1, so it decays (as upstream)
+
+
+def test_cosine_schedule_matches_the_transformers_implementation():
+    from transformers.optimization import get_cosine_schedule_with_warmup
+    from otter_amd.trainer import cosine_with_warmup
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1.0)
+    sched = get_cosine_schedule_with_warmup(opt, num_warmup_steps=5, num_training_steps=40)
+    for step in range(45):
+        assert abs(opt.param_groups[0]["lr"] - cosine_with_warmup(step, 5, 40)) < 1e-12
+        opt.step()
+        sched.step()
+
+
+def test_loss_scale_state_machine():
+    from otter_amd.trainer import LossScale
+    s = LossScale(growth_interval=3)
+    assert s.scale == 65536.0
+    s.update(True)
+    assert s.scale == 32768.0
+    for _ in range(3):
+        s.update(False)
+    assert s.scale == 65536.0
+    s.update(False); s.update(True); s.update(False); s.update(False)
+    assert s.scale == 32768.0                                    # the clean-step counter restarted after the overflow
+    t = LossScale()
+    t.load_state_dict(s.state_dict())
+    assert t.scale == s.scale
+    assert LossScale(enabled=False).scale == 1.0
+
+
+def test_flatten_parameters_aliases_the_module():
+    from otter_amd.trainer import add_weight_decay, bucket_bounds, flatten_parameters
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.LayerNorm(3))
+    before = {n: p.detach().clone() for n, p in lin.named_parameters()}
+    groups = add_weight_decay(lin, 0.1)
+    flat, spans, where = flatten_parameters(groups)
+    assert flat.numel() == 4 * 64 and spans == [(0, 192, 0.0), (192, 256, 0.1)]       # every tensor starts on a 64-element boundary
+    for n, p in lin.named_parameters():
+        assert torch.equal(p.detach(), before[n])
+        lo, hi = where[id(p)]
+        assert p.data_ptr() == flat[lo:hi].data_ptr()
+    flat.zero_()
+    assert all(float(p.abs().sum()) == 0 for p in lin.parameters())
+    assert bucket_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]

@@ -73,3 +73,23 @@ def test_single_rank_passthrough():
     x = torch.zeros(3, 12, 10)
     assert gather_actions(x, 3, 0, 1) is x
     assert timed_region(lambda: None, 3) >= 0.0
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from otter_amd.trainer import allreduce_flat
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # rank r holds (r+1) * [0..999]
+        allreduce_flat(flat, bucket_elems=300)                               # 4 buckets, the last one short
+        torch.save(flat, os.path.join(out_dir, f"g{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_exchange_two_ranks_gloo(tmp_path):
+    """Data-parallel gradient exchange of the training step: bucketed SUM all-reduce of the flat gradient buffer."""
+    mp.spawn(_grad_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = torch.arange(1000, dtype=torch.float32) * 3
+    for r in range(2):
+        assert torch.equal(torch.load(tmp_path / f"g{r}.pt"), want)

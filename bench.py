@@ -118,22 +118,34 @@ def measure_kernels(work, steps: int):
 
     def timed(kind, fn, flops_or_bytes):
         def wrapper(*a, **k):
-            if kind == "gemm" and a[0].dtype == torch.float32:      # small fp32 layers after the towers: not the MFMA-bound kernel
-                return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(*a, **k)
             e1.record()
-            rec[kind].append((e0, e1, flops_or_bytes(a, k, out)))
+            rec[kind].append((e0, e1, flops_or_bytes(a, k, out), 0.0))
             return out
         return wrapper
 
-    def gemm_flops(a, k, out):
-        # algorithmic FLOPs: 2*M*N*K with the un-padded K where the operand was padded (patch embedding: 588 of 640)
-        m, kk = a[0].shape
-        n = a[2]
-        k_real = 588 if kk == 640 else kk
-        return 2.0 * m * n * k_real
+    def gemm_wrapper(a, wp, n, bias=None, *, act=0, out_f32=False, residual=None, out=None, force_tile_128=False):
+        """Times the dominant kernel only: a big 16-bit GEMM is issued as its whole 256-row tiles (the 256x256 kernel, timed)
+        and its remainder rows (the 64x64 kernel, not timed) -- rows are independent, so the results are those of one call."""
+        m, kk = a.shape
+        if a.dtype == torch.float32 or m < 1024 or n < 256 or force_tile_128:
+            return real_gemm(a, wp, n, bias, act=act, out_f32=out_f32, residual=residual, out=out, force_tile_128=force_tile_128)
+        m_main = m // 256 * 256
+        if out is None:
+            out = torch.empty(m, n, dtype=torch.float32 if (out_f32 or residual is not None) else a.dtype, device=a.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_gemm(a[:m_main], wp, n, bias, act=act, out_f32=out_f32, residual=None if residual is None else residual[:m_main], out=out[:m_main])
+        e1.record()
+        k_real = 588 if kk == 640 else kk          # algorithmic FLOPs: the un-padded K of the patch embedding
+        out_bytes = 4 if (out_f32 or residual is not None) else 2
+        nbytes = m_main * kk * 2 + n * kk * 2 + m_main * n * out_bytes + (m_main * n * 4 if residual is not None else 0)
+        rec["gemm"].append((e0, e1, 2.0 * m_main * n * k_real, float(nbytes)))
+        if m_main < m:
+            real_gemm(a[m_main:], wp, n, bias, act=act, out_f32=out_f32, residual=None if residual is None else residual[m_main:], out=out[m_main:])
+        return out
 
     def tave_bytes(a, k, out):
         # compulsory traffic per (observation, camera): patches in (bf16) + text in + out (fp32 here)
@@ -143,7 +155,7 @@ def measure_kernels(work, steps: int):
         kq = text.shape[1]
         return units * (p * d * 2 + kq * d * 4 + kq * d * 4)
 
-    ops.gemm = timed("gemm", real_gemm, gemm_flops)
+    ops.gemm = gemm_wrapper
     ops.text_aware_pool = timed("tave", real_tave, tave_bytes)
     try:
         for _ in range(steps):
@@ -153,10 +165,9 @@ def measure_kernels(work, steps: int):
         ops.gemm, ops.text_aware_pool = real_gemm, real_tave
     out = {}
     for kind, items in rec.items():
-        ms = [e0.elapsed_time(e1) for e0, e1, _ in items]
-        work_units = [w for _, _, w in items]
-        out[kind] = dict(launches=len(items), total_ms=float(sum(ms)), total_work=float(sum(work_units)),
-                         big=[(m_, w_) for m_, w_ in zip(ms, work_units)])
+        ms = [e0.elapsed_time(e1) for e0, e1, _, _ in items]
+        out[kind] = dict(launches=len(items), total_ms=float(sum(ms)), total_work=float(sum(w for _, _, w, _ in items)),
+                         total_bytes=float(sum(b for _, _, _, b in items)))
     return out
 
 
@@ -235,8 +246,15 @@ def main():
             gm = k["gemm"]
             # dominant kernel: the bf16 MFMA GEMM (CLIP tower launches are >99.9% of its FLOPs)
             tf = gm["total_work"] / (gm["total_ms"] * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "kernel": "gemm_256x256 + remainder-row gemm_64x64 (16-bit operands, CLIP towers)", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": None,
+            traffic = None                      # HBM-side bytes per launch from the PMC passes of this same command (profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as fh:
+                    traffic = json.load(fh)["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
+            result["roofline"] = {"bound": "mfma", "kernel": "gemm_256x256 (16-bit operands, CLIP towers; whole 256-row tiles)", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": traffic,
+                                  "algorithmic_bytes_per_launch": gm["total_bytes"] / gm["launches"],
                                   "launches": gm["launches"], "avg_launch_us": 1e3 * gm["total_ms"] / gm["launches"],
                                   "gemm_ms_per_step": gm["total_ms"] / 2}
             tv = k["tave"]

@@ -137,14 +137,29 @@ class ClipDevice:
         return feats.view(n, p + 1, self.embed), p, self.embed
 
     # -- text --------------------------------------------------------------------------------
-    def text_tokens(self, ids: Tensor) -> Tensor:
-        """ids (B, ctx) int32 on the device -> fp32 (B, first_k, embed), projected, un-normalised."""
+    def text_tokens(self, ids: Tensor, pooled_row: bool = False) -> Tensor:
+        """ids (B, ctx) int32 on the device -> fp32 (B, first_k, embed), projected, un-normalised.
+
+        With ``pooled_row`` one more row is appended per prompt: CLIP's pooled text feature, i.e. ``ln_final`` +
+        ``text_projection`` of the end-of-text position (``encode_text``; the OpenCLIP extraction script adds it as a 16th
+        query, ``script/open_clip_visualization.py:62-64,108-109``).  The tower then runs up to the last end-of-text
+        position of the batch instead of ``first_k`` (exact under the causal mask either way).
+        """
         b = ids.shape[0]
         k = self.first_k
-        x = ops.text_embed(ids, k, self.tok_emb, self.tpos)
-        x = self._run_blocks(x, self.tblocks, b, k, self.t_heads, True, False)
+        take = k
+        eot = None
+        if pooled_row:
+            eot = ids.argmax(dim=-1)                                   # end-of-text has the highest id (49407)
+            take = max(k, int(eot.max().item()) + 1)
+        x = ops.text_embed(ids, take, self.tok_emb, self.tpos)
+        x = self._run_blocks(x, self.tblocks, b, take, self.t_heads, True, False)
         h = ops.layernorm(x, *self.ln_final, out_dtype=self.dtype)
-        return ops.gemm(h, self.w_tproj, self.embed, None, out_f32=True).view(b, k, self.embed)
+        feats = ops.gemm(h, self.w_tproj, self.embed, None, out_f32=True).view(b, take, self.embed)
+        if not pooled_row:
+            return feats
+        rows = torch.cat([torch.arange(k, device=ids.device).expand(b, k), eot[:, None]], dim=1)        # (B, k+1) positions
+        return torch.gather(feats, 1, rows[:, :, None].expand(b, k + 1, self.embed)).contiguous()
 
     def text_tokens_cached(self, ids_host: Tensor) -> Tensor:
         """Host token rows (B, ctx) int32 -> device features, running the tower once per distinct prompt."""

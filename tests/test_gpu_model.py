@@ -148,3 +148,82 @@ def test_batched_rollout_equals_single_episode(dev):
     fresh = BatchedRollout(d, 1)
     torch.testing.assert_close(nxt[1], fresh.step(images[0, 1], tf[1:2], proprio[0, 1:2]).cpu()[0], rtol=1e-3, atol=2e-4)
     assert list(batch.lens_host) == [sc.seq_length, 1, sc.seq_length]
+
+
+def test_openclip_gelu_backbone_text_aware_extraction(dev):
+    """OpenCLIP ViT-L/14 variant (GELU instead of QuickGELU; script/open_clip_visualization.py:38-117): per (image, prompt)
+    pair, 15 text-token queries plus the pooled text feature as a 16th query, softmax temperature 0.005.
+    Four pairs against the fp32 CPU oracle, then the same pairs inside a batch of 256 (one GPU's share of the batch-256
+    extraction): results do not depend on the batch they are computed in."""
+    from otter_amd import ops
+    from otter_amd.config import ModelConfig, SharedConfig, clip_arch
+    from otter_amd.device_model import CLIP_MEAN, CLIP_STD, ClipDevice
+    from otter_amd.params import otter_specs, random_state_dict, sincos_position_embedding
+    mc, sc = ModelConfig(clip_model="open_clip:ViT-L-14"), SharedConfig()
+    arch = clip_arch(mc.clip_model)
+    assert arch.activation == "gelu"
+    sd = random_state_dict(otter_specs(mc, sc), seed=3)
+    clip = ClipDevice({k: v for k, v in sd.items() if k.startswith("clip_model.")}, arch, 15, dev)
+    rng = np.random.default_rng(11)
+    n_big, n_small = 256, 4
+    images = torch.from_numpy(rng.integers(0, 256, (n_big, 3, 224, 224), dtype=np.uint8))
+    text = GI._tokens(rng, n_big, (3, 5, 8, 11, 17))                       # the 17-token prompt ends past the first 15 positions
+    pos = sincos_position_embedding(256, 768)
+    temp = torch.tensor([0.005])
+    pos_t = ops.pos_emb_transpose(pos.to(dev), torch.float16)[None].contiguous()
+
+    def extract(n):
+        tokens, p, d = clip.vision_tokens(images[:n].to(dev))
+        tf = clip.text_tokens(text[:n].to(dev), pooled_row=True)           # (n, 16, D)
+        assert tf.shape == (n, 16, d)
+        return ops.text_aware_pool(tokens, tf, pos_t, temp.to(dev), n, 1, 1, n_patches=p)[0], tf
+
+    small, tf_small = extract(n_small)
+    with torch.no_grad():
+        x = R.clip_transform(images[:n_small])
+        pf = clip_ref.patch_features(x, sd, "clip_model.", clip_ref.gelu_erf)                       # (4, 256, 768) normalised
+        tf = clip_ref.text_features(text[:n_small], 15, sd, "clip_model.", clip_ref.gelu_erf)        # (4, 15, 768) normalised
+        pooled = clip_ref.encode_text(text[:n_small], sd, "clip_model.", clip_ref.gelu_erf)
+        pooled = pooled / pooled.norm(dim=-1, keepdim=True)
+        tf16 = torch.cat([tf, pooled[:, None]], dim=1)
+        ref = R.text_aware_visual_extraction(pf, tf16, temp[0], pos)
+    got_tf = tf_small.cpu() / tf_small.cpu().norm(dim=-1, keepdim=True)
+    assert _cos(got_tf, tf16) >= 0.9999
+    assert _cos(got_tf[:, 15], tf16[:, 15]) >= 0.9999                      # the pooled row on its own
+    err = (small.cpu() - ref).abs().max().item()
+    print(f"OpenCLIP-variant extraction: cosine {_cos(small.cpu(), ref):.6f}, max abs err {err:.2e} (|ref| max {ref.abs().max():.2f})")
+    # temperature 0.005 turns a 1e-4 error of a cosine into 2 % of a softmax weight: see the kernel-level test
+    assert _cos(small.cpu(), ref) >= 0.9999 and err <= 2e-2
+    big, _ = extract(n_big)
+    assert torch.equal(big[:n_small], small)                               # batch-size independent, bit for bit
+    assert torch.isfinite(big).all()
+
+
+def test_long_history_rollout_64_episodes_window_32(dev):
+    """Long-horizon configuration: 64 concurrent episodes per GPU, history window 32, cached K/V while the window fills
+    and recompute once it slides.  Two of the episodes against single-episode rollouts of the CPU oracle."""
+    from otter_amd.config import ModelConfig, SharedConfig
+    from otter_amd.engine import BatchedRollout
+    mc = ModelConfig(clip_model="tiny-test", transformer_dim=128, transformer_layers=2, transformer_heads=2, vision_pooling_output_dim=128,
+                     text_pooling_output_dim=64, proprio_hidden_dim=64, proprio_output_dim=32, pooling_heads=4)
+    sc = SharedConfig(image_size=112, seq_length=32, action_horizon=4)
+    model, sd = _model(mc, sc, 21, dev)
+    d = model.device_model()
+    B, steps = 64, 36
+    rng = np.random.default_rng(13)
+    images = torch.from_numpy(rng.integers(0, 256, (steps, B, 2, 3, 112, 112), dtype=np.uint8))
+    proprio = torch.from_numpy(rng.standard_normal((steps, B, 10)).astype(np.float32))
+    text = GI._tokens(rng, B, (4, 7, 9))
+    tf = d.clip.text_tokens_cached(text)
+    batch = BatchedRollout(d, B)
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length)
+    oracles = {e: R.Rollout(sd, dims) for e in (0, 63)}
+    worst = 0.0
+    for t in range(steps):
+        got = batch.step(images[t].reshape(B * 2, 3, 112, 112).to(dev), tf, proprio[t].to(dev)).cpu()
+        for e, ro in oracles.items():
+            ref = ro.step(R.clip_transform(images[t, e]), text[e], proprio[t, e])
+            worst = max(worst, (got[e] - ref).abs().max().item())
+    print(f"64 episodes x window 32: max |action - oracle| over {steps} steps = {worst:.2e}")
+    assert worst <= 1e-3

@@ -80,13 +80,18 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
         const int q = qt * 16 + li;                // this lane's query
         // Every key tile is computed, also rows past L: a wave-uniform skip here would put a branch between an
         // MFMA and the first read of its accumulator.
+        // The K fragments do not depend on the query tile; left alone the compiler keeps all of them in registers
+        // across the loop (2*NT*4 = 136 VGPRs), which leaves too few to keep the V^T reads of the second product in
+        // flight.  An opaque copy of the row offset keeps the (cheap) LDS reads inside the loop.
+        int k_row = k_row_off;
+        asm volatile("" : "+v"(k_row));
         f32x4 s[NT];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const v8 kf = *(const v8*)(sK + kt * 2048 + k_row_off + (((ks * 4 + g) ^ k_sw) << 4));
+                const v8 kf = *(const v8*)(sK + kt * 2048 + k_row + (((ks * 4 + g) ^ k_sw) << 4));
                 s[kt] = Half16<T>::mfma32(kf, qf[ks], s[kt]);
             }
         }

@@ -29,8 +29,8 @@ __device__ __forceinline__ int v_swz(int row, int chunk) { return chunk ^ (((row
 // NT = number of 16-key tiles computed (also the number of 16-query tiles); LS = the sequence length when it is
 // known at compile time (0: taken from the arguments).  With LS the validity of every key is a compile-time fact
 // except in the last, partial tile, so the softmax carries no masking work for the full tiles.
-template <typename T, int NT, int LS>
-__global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
+template <typename T, int NT, int LS, int NW>      // NW waves per workgroup share the query tiles
+__global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 v8;
     typedef typename Half16<T>::v4 v4;
@@ -56,11 +56,11 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
             qf[ks] = *(const v8*)(qkv + (row0 + qc) * p.ld + h * 64 + ks * 32 + g * 8);
     };
     v8 qf[2];
-    load_q(wave, qf);
+    load_q(wave < NT ? wave : 0, qf);
 
     // ---- stage K and V of this head by LDS-DMA: one instruction = 8 rows x 128 bytes, lane-linear destination, the
     //      chunk swizzle applied on the source address.  Rows >= L repeat row L-1 (finite data; their keys are masked). ----
-    for (int grp = wave; grp < LK / 8; grp += 4) {
+    for (int grp = wave; grp < LK / 8; grp += NW) {
         const int r = grp * 8 + (lane >> 3), pc = lane & 7;
         const T* base = qkv + (row0 + min(r, L - 1)) * p.ld + h * 64;
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + hd + (k_swz(r, pc) << 3)), LDS_PTR(sK + grp * 1024), 16, 0, 0);
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
     const int vr = li >> 2;
     const float c2 = p.scale * 1.44269504088896341f;     // softmax(scale*s) = 2^(c2*s - c2*max) / sum
 
-    for (int qt = wave; qt < NT; qt += 4) {
+    for (int qt = wave; qt < NT; qt += NW) {
         const int q = qt * 16 + li;                // this lane's query
         // Every key tile is computed, also rows past L: a wave-uniform skip here would put a branch between an
         // MFMA and the first read of its accumulator.
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
                 s[kt] = Half16<T>::mfma32(kf, qf[ks], s[kt]);
             }
         }
-        if (qt + 4 < NT) load_q(qt + 4, qf);        // lands while the softmax runs
+        if (qt + NW < NT) load_q(qt + NW, qf);      // lands while the softmax runs
 
         // ---- mask + softmax over keys (per lane: one query).  Key kt*16 + 4g + r is valid iff kt*16 + r < lim. ----
         const int lim = (causal ? min(L, q + 1) : L) - 4 * g;
@@ -165,16 +165,16 @@ __global__ __launch_bounds__(256) void attn_d64(AttnArgs p) {
     }
 }
 
-template <typename T, int NT, int LS>
+template <typename T, int NT, int LS, int NW = 4>
 int launch_d64(const AttnArgs& a, int n_seq, hipStream_t s) {
     constexpr int lds = NT * 16 * 128 * 2;
-    auto kern = attn_d64<T, NT, LS>;
+    auto kern = attn_d64<T, NT, LS, NW>;
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3(n_seq * a.heads), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(n_seq * a.heads), dim3(NW * 64), lds, s, a);
     OTTER_CHECK_LAUNCH("otter_attn_fwd_d64");
     return OTTER_OK;
 }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_policy(PolicyAttnArgs p, int total) 
 
 template <typename T>
 static int dispatch_d64(const AttnArgs& a, int n_seq, int L, hipStream_t s) {
-    if (L == 257 && !a.causal) return launch_d64<T, 17, 257>(a, n_seq, s);      // ViT-L/14 and ViT-B/... at 224: 256 patches + CLS
+    if (L == 257 && !a.causal) return launch_d64<T, 17, 257, 4>(a, n_seq, s);    // 4 waves measured faster than 5 or 6 (79 vs 88 / 82 us per layer)      // ViT-L/14 and ViT-B/... at 224: 256 patches + CLS
     if (L <= 32) return launch_d64<T, 2, 0>(a, n_seq, s);
     if (L <= 96) return launch_d64<T, 6, 0>(a, n_seq, s);
     return launch_d64<T, 18, 0>(a, n_seq, s);

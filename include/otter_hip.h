@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 3
+#define OTTER_HIP_ABI_VERSION 4
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -99,10 +99,14 @@ int otter_attn_policy(const float* qkv, long ld, float* out, long ldo, int batch
  * patches: un-normalised projected patch tokens; unit u = m*cams + c is the row-major [P][D] block at
  *   patches + u*unit_stride (unit_stride in elements, >= P*D; lets the caller skip the class-token row);
  * text: fp32 [n_obs/t_rep][K][D] un-normalised projected text tokens (observation m uses row m / t_rep);
- * posT: [cams][D][P] from otter_pos_emb_transpose; out: fp32 [cams][n_obs][K][D].  K <= 16, P % 16 == 0. */
-int otter_text_aware_pool_fwd(int dtype, const void* patches, long unit_stride, const float* text, const void* posT, const float* temperature,
-                              float* out, int n_obs, int cams, int P, int D, int K, int t_rep, void* stream);
-int otter_pos_emb_transpose(int dtype, const float* pos /* [P][D] fp32 */, void* posT /* [D][P] bf16|fp16 */, int P, int D, void* stream);
+ * pos_packed: [cams][P*D], every camera's pos_emb packed by otter_pos_emb_pack; out: fp32 [cams][n_obs][K][D].
+ * K <= 16, P % 16 == 0, D in {128, 512, 768, 1024}. */
+int otter_text_aware_pool_fwd(int dtype, const void* patches, long unit_stride, const float* text, const void* pos_packed,
+                              const float* temperature, float* out, int n_obs, int cams, int P, int D, int K, int t_rep,
+                              void* stream);
+/* pos_emb buffer (sincos_position_embedding, models.py:5-12,19-20) [P][D] fp32 -> 16-bit table in the order the
+ * pooling kernel's lanes read it (16-byte coalesced loads). */
+int otter_pos_emb_pack(int dtype, const float* pos /* [P][D] fp32 */, void* packed /* [P*D] bf16|fp16 */, int P, int D, void* stream);
 
 /* Query side of AttentionPooling (otter/policy/transformer.py:162-232) after the k/v projections.
  * All weights fp32, matrices transposed to [in][out]. */

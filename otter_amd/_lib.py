@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
@@ -42,7 +42,7 @@ _SIGNATURES = {
     "otter_attn_fwd_d64": [_I, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "otter_attn_policy": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "otter_text_aware_pool_fwd": [_I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "otter_pos_emb_transpose": [_I, _P, _P, _I, _I, _P],
+    "otter_pos_emb_pack": [_I, _P, _P, _I, _I, _P],
     "otter_readout_pool_fwd": [POINTER(ReadoutBlock), _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "otter_l2norm_rows": [_I, _P, _L, _P, _L, _I, _I, _P],
     "otter_linear_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],

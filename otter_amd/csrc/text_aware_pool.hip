@@ -14,8 +14,9 @@
 //   * online softmax over patches (running max / sum per text token, one text token per lane);
 //   * O^T += X^T . (p/|x|)  +  pos^T . p   with v_mfma_f32_16x16x16: the S^T accumulator layout
 //     (patch 4g+r on the registers, text token on the lane) is exactly that instruction's B operand, X^T comes
-//     from the row-major LDS tile by ds_read_b64_tr_b16, and pos^T is a pre-transposed 16-bit table read from L2
-//     (loads issued at the top of the tile, used at its end).  Each wave owns D/4 output columns.
+//     from the row-major LDS tile by ds_read_b64_tr_b16, and pos^T comes from a 16-bit copy of pos_emb packed in
+//     fragment order (otter_pos_emb_pack), so each lane fetches two d-tiles with one coalesced 16-byte load from
+//     L2 (issued at the top of the tile, used at its end).  Each wave owns D/4 output columns.
 // LDS rows are D*2 bytes (a multiple of 256), so the 16-byte chunk index is XORed with f(row) (below) which
 // makes both the ds_read_b128 fragment reads and the transposed reads bank-conflict free.  The LDS image is
 // lane-linear (LDS-DMA requirement); the swizzle is applied to the per-lane source address.
@@ -30,7 +31,7 @@ struct TaveArgs {
     const void* patches;        // unit u at patches + u*unit_stride, [P][D] row-major, bf16 or fp16
     long unit_stride;
     const float* text;          // [n_text][K][D]
-    const void* posT;           // [cams][D][P]  (pos_emb transposed, same 16-bit type as the patches)
+    const void* posF;           // [cams][P/16][4 waves][NDT/2][64 lanes][8]: pos_emb in MFMA-fragment order (otter_pos_emb_pack)
     const float* temperature;   // [cams]
     float* out;                 // [cams][M][K][D]
     int units, cams, P, D, K, t_rep, M;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
     const int m = unit / p.cams, cam = unit % p.cams;
     const int P = p.P, nt = P >> 4;
     const T* X = (const T*)p.patches + (long)unit * p.unit_stride;
-    const T* posT = (const T*)p.posT + (long)cam * D * P;
+    const T* posF = (const T*)p.posF + (long)cam * P * D;
 
     // ---- per-lane LDS-DMA source offsets (bytes within a tile), identical for every tile ----
     int src_off[NLD];
@@ -88,7 +89,8 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
     // ---- text rows: L2-normalise in fp32, store as 16-bit (swizzled) ; rows >= K are zero ----
     {
         const int b = m / p.t_rep;
-        for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {                 // unrolled: the loads of the wave's four rows are in flight together
             const int r = wave * 4 + rr;
             const float* src = p.text + ((long)b * p.K + r) * D;
             float sq = 0.f;
@@ -142,14 +144,15 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const char* xb = sX + (t % NST) * TILE_B;
 
-        // pos^T of this tile for the wave's columns (L2-resident table): issued first, consumed after the similarity phase
-        // (issued from inline asm: the compiler would wait for them with vmcnt(0), draining the tile prefetch that is
-        //  issued right after; the counted wait before their first use is placed by hand below)
-        s16x4 pt[NDT];
+        // pos_emb of this tile for the wave's columns, pre-packed in fragment order: one coalesced 16-byte load per lane
+        // covers two d-tiles (L2-resident table).  Issued first, consumed after the similarity phase; from inline asm
+        // because the compiler would wait for them with vmcnt(0), draining the tile prefetch issued right after --
+        // the counted wait before their first use is placed by hand below.
+        s16x8 pt[NDT / 2];
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const T* src = posT + (long)((wave * NDT + dt) * 16 + li) * P + t * 16 + 4 * g;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pt[dt]) : "v"(src) : "memory");
+        for (int dp = 0; dp < NDT / 2; ++dp) {
+            const T* src = posF + ((long)t * 4 + wave) * (NDT * 256) + (dp * 64 + lane) * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pt[dp]) : "v"(src) : "memory");
         }
         if constexpr (PREFETCH) stage((t + 2) % NST, t + 2);
 
@@ -206,9 +209,9 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
         // the pos^T loads are older than the NLD prefetch instructions issued after them (in-order retirement);
         // the "+v" operands tie every later use of pt[] to this wait
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            if constexpr (PREFETCH) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pt[dt]) : "n"(NLD) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pt[dt]) : : "memory");
+        for (int dp = 0; dp < NDT / 2; ++dp) {
+            if constexpr (PREFETCH) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pt[dp]) : "n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pt[dp]) : : "memory");
         }
         // X^T fragments by ds_read_b64_tr_b16, also from inline asm: after an LDS-DMA the compiler puts vmcnt(0) in
         // front of the builtin form of this read (it cannot tell that the buffers differ), draining the prefetch
@@ -225,7 +228,9 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             o[dt] = Half16<T>::mfma16(xt[dt], b1, o[dt]);
-            o[dt] = Half16<T>::mfma16(pt[dt], b2, o[dt]);
+            const s16x8 pp2 = pt[dt >> 1];
+            const s16x4 ph = (dt & 1) ? (s16x4){pp2[4], pp2[5], pp2[6], pp2[7]} : (s16x4){pp2[0], pp2[1], pp2[2], pp2[3]};
+            o[dt] = Half16<T>::mfma16(ph, b2, o[dt]);
         }
     };
     {
@@ -268,13 +273,20 @@ int launch_tave(const TaveArgs& a, hipStream_t s) {
     return OTTER_OK;
 }
 
+// pos_emb [P][D] fp32 -> 16-bit table in the order tave_kernel's lanes consume it:
+//   packed[((t*4 + w)*(NDT/2) + dp)*64 + lane][h*4 + j] = pos[16t + 4g + j][(w*NDT + 2dp + h)*16 + li],  g = lane>>4, li = lane&15
+// (setup-time kernel, one thread per element)
 template <typename T>
-__global__ void pos_transpose_kernel(const float* pos, T* posT, int P, int D) {
-    // posT[d][k] = T(pos[k][d]); one thread per output element (setup-time kernel)
+__global__ void pos_pack_kernel(const float* pos, T* packed, int P, int D) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)P * D) return;
-    const int d = (int)(i / P), k = (int)(i % P);
-    posT[i] = Half16<T>::from(pos[(long)k * D + d]);
+    const int ndt = D / 64;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    long rest = i >> 9;
+    const int dp = (int)(rest % (ndt / 2)); rest /= (ndt / 2);
+    const int w = (int)(rest & 3), t = (int)(rest >> 2);
+    const int h = e >> 2, j = e & 3, g = lane >> 4, li = lane & 15;
+    packed[i] = Half16<T>::from(pos[(long)(16 * t + 4 * g + j) * D + (w * ndt + 2 * dp + h) * 16 + li]);
 }
 
 template <typename T>
@@ -291,33 +303,35 @@ int dispatch_tave(const TaveArgs& a, int D, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int otter_text_aware_pool_fwd(int dtype, const void* patches, long unit_stride, const float* text, const void* posT, const float* temperature,
-                                         float* out, int n_obs, int cams, int P, int D, int K, int t_rep, void* stream) {
+extern "C" int otter_text_aware_pool_fwd(int dtype, const void* patches, long unit_stride, const float* text, const void* pos_packed,
+                                         const float* temperature, float* out, int n_obs, int cams, int P, int D, int K, int t_rep,
+                                         void* stream) {
     OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: dtype %d (bf16 or fp16)", dtype);
-    OTTER_REQUIRE(patches && text && posT && temperature && out, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: null operand");
+    OTTER_REQUIRE(patches && text && pos_packed && temperature && out, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: null operand");
     if (n_obs == 0) return OTTER_OK;
     OTTER_REQUIRE(n_obs > 0 && cams > 0 && t_rep > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: bad sizes");
     OTTER_REQUIRE(n_obs % t_rep == 0, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: n_obs=%d not a multiple of t_rep=%d", n_obs, t_rep);
     OTTER_REQUIRE(K >= 1 && K <= 16, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_fwd: K=%d text tokens, supports 1..16", K);
     OTTER_REQUIRE(P >= 16 && P % 16 == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_fwd: P=%d must be a multiple of 16", P);
-    OTTER_REQUIRE(aligned16(patches) && aligned16(text) && aligned16(posT) && aligned16(out), OTTER_ERR_ALIGNMENT,
+    OTTER_REQUIRE(aligned16(patches) && aligned16(text) && aligned16(pos_packed) && aligned16(out), OTTER_ERR_ALIGNMENT,
                   "otter_text_aware_pool_fwd: operands must be 16-byte aligned");
     OTTER_REQUIRE((long)n_obs * cams < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_fwd: grid too large");
     OTTER_REQUIRE(unit_stride >= (long)P * D && unit_stride % 8 == 0, OTTER_ERR_ALIGNMENT,
                   "otter_text_aware_pool_fwd: unit_stride=%ld must be >= P*D and a multiple of 8 elements", unit_stride);
-    TaveArgs a{patches, unit_stride, text, posT, temperature, out, n_obs * cams, cams, P, D, K, t_rep, n_obs};
+    TaveArgs a{patches, unit_stride, text, pos_packed, temperature, out, n_obs * cams, cams, P, D, K, t_rep, n_obs};
     hipStream_t s = (hipStream_t)stream;
     return dtype == DT_BF16 ? dispatch_tave<__bf16>(a, D, s) : dispatch_tave<_Float16>(a, D, s);
 }
 
-extern "C" int otter_pos_emb_transpose(int dtype, const float* pos, void* posT, int P, int D, void* stream) {
-    OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_pos_emb_transpose: dtype %d (bf16 or fp16)", dtype);
-    OTTER_REQUIRE(pos && posT && P > 0 && D > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_pos_emb_transpose: bad arguments");
+extern "C" int otter_pos_emb_pack(int dtype, const float* pos, void* packed, int P, int D, void* stream) {
+    OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_pos_emb_pack: dtype %d (bf16 or fp16)", dtype);
+    OTTER_REQUIRE(pos && packed && P > 0 && D > 0 && P % 16 == 0 && D % 128 == 0, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_pos_emb_pack: bad arguments (P %% 16 == 0, D %% 128 == 0)");
     const long n = (long)P * D;
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL(pos_transpose_kernel<__bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (__bf16*)posT, P, D);
+        hipLaunchKernelGGL(pos_pack_kernel<__bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (__bf16*)packed, P, D);
     else
-        hipLaunchKernelGGL(pos_transpose_kernel<_Float16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (_Float16*)posT, P, D);
-    OTTER_CHECK_LAUNCH("otter_pos_emb_transpose");
+        hipLaunchKernelGGL(pos_pack_kernel<_Float16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (_Float16*)packed, P, D);
+    OTTER_CHECK_LAUNCH("otter_pos_emb_pack");
     return OTTER_OK;
 }

@@ -256,7 +256,7 @@ class OtterDevice:
         self.text_pool = PoolingWeights(sdd, "text_pooling.", pooling_heads)
         self.vis_pool = [PoolingWeights(sdd, f"vision_poolings.{c}.", pooling_heads) for c in range(num_cameras)]
         self.temperature = torch.stack([sdd[f"visual_extraction.{c}.temperature"].float() for c in range(num_cameras)]).contiguous()
-        self.pos_t = torch.stack([ops.pos_emb_transpose(_f32(sdd[f"visual_extraction.{c}.pos_emb"], self.device), clip_dtype)
+        self.pos_t = torch.stack([ops.pos_emb_pack(_f32(sdd[f"visual_extraction.{c}.pos_emb"], self.device), clip_dtype)
                                   for c in range(num_cameras)]).contiguous()
         self.prop = [(_f32(sdd[f"proprio_encoder.mlp.{i}.weight"].t(), self.device), _f32(sdd[f"proprio_encoder.mlp.{i}.bias"], self.device))
                      for i in (0, 2, 4)]

@@ -220,43 +220,45 @@ def attn_policy(qkv_cache: Tensor, n_query: int, pos0: int, heads: int) -> Tenso
     return out
 
 
-def pos_emb_transpose(pos: Tensor, dtype=torch.bfloat16) -> Tensor:
+def pos_emb_pack(pos: Tensor, dtype=torch.bfloat16) -> Tensor:
+    """pos_emb (P, D) fp32 -> (P*D,) 16-bit table in the order the pooling kernel's lanes read it."""
     _chk(pos, torch.float32, "pos_emb", 2)
     if not pos.is_contiguous():
         raise ValueError("pos_emb must be contiguous")
     p, d = pos.shape
-    out = torch.empty(d, p, dtype=dtype, device=pos.device)
-    _lib.call("otter_pos_emb_transpose", _dt(dtype, "pos_emb.dtype", False), _ptr(pos), _ptr(out), p, d, _stream())
+    out = torch.empty(p * d, dtype=dtype, device=pos.device)
+    _lib.call("otter_pos_emb_pack", _dt(dtype, "pos_emb_pack", False), _ptr(pos), _ptr(out), p, d, _stream())
     return out
 
 
-def text_aware_pool(patches: Tensor, text: Tensor, pos_t: Tensor, temperature: Tensor, n_obs: int, cams: int, t_rep: int,
+def text_aware_pool(patches: Tensor, text: Tensor, pos_packed: Tensor, temperature: Tensor, n_obs: int, cams: int, t_rep: int,
                     n_patches: Optional[int] = None) -> Tensor:
     """Fused text-aware visual extraction.
 
     patches bf16/fp16: either (n_obs*cams, P, D) contiguous, or (n_obs*cams, L, D) with ``n_patches`` = P < L given,
     in which case the LAST P rows of each unit are used (skips the class token of a ViT output);
-    text fp32 (n_obs/t_rep, K, D); pos_t (cams, D, P) of the patches' dtype; -> fp32 (cams, n_obs, K, D).
+    text fp32 (n_obs/t_rep, K, D); pos_packed (cams, P*D) from :func:`pos_emb_pack` in the patches' dtype;
+    -> fp32 (cams, n_obs, K, D).
     """
     dt = _dt(patches.dtype, "tave.patches", False)
     _chk(patches, patches.dtype, "tave.patches", 3)
     _chk(text, torch.float32, "tave.text", 3)
-    _chk(pos_t, patches.dtype, "tave.posT", 3)
+    _chk(pos_packed, patches.dtype, "tave.pos_packed", 2)
     _chk(temperature, torch.float32, "tave.temperature", 1)
     units, rows, d = patches.shape
     p = n_patches if n_patches is not None else rows
     nt, k, d2 = text.shape
     if units != n_obs * cams or d2 != d or n_obs % t_rep != 0 or nt != n_obs // t_rep or p > rows:
         raise ValueError(f"tave: patches {tuple(patches.shape)}, text {tuple(text.shape)}, n_obs={n_obs}, cams={cams}, t_rep={t_rep}")
-    if tuple(pos_t.shape) != (cams, d, p) or temperature.numel() != cams:
-        raise ValueError("tave: pos_t / temperature shape mismatch")
-    for t in (patches, text, pos_t, temperature):
+    if tuple(pos_packed.shape) != (cams, p * d) or temperature.numel() != cams:
+        raise ValueError("tave: pos_packed / temperature shape mismatch")
+    for t in (patches, text, pos_packed, temperature):
         if not t.is_contiguous():
             raise ValueError("tave: operands must be contiguous")
     out = torch.empty(cams, n_obs, k, d, dtype=torch.float32, device=patches.device)
     base = ctypes.c_void_p(patches.data_ptr() + (rows - p) * d * 2)
-    _lib.call("otter_text_aware_pool_fwd", dt, base, rows * d, _ptr(text), _ptr(pos_t), _ptr(temperature), _ptr(out), n_obs, cams,
-              p, d, k, t_rep, _stream())
+    _lib.call("otter_text_aware_pool_fwd", dt, base, rows * d, _ptr(text), _ptr(pos_packed), _ptr(temperature), _ptr(out),
+              n_obs, cams, p, d, k, t_rep, _stream())
     return out
 
 

@@ -161,7 +161,7 @@ class TrainableTail:
             q_t, q_v = self.params["text_pooling.query"], self.params["vision_poolings.0.query"]
             d_text, d_vis = q_t.shape[1] * q_t.shape[2], q_v.shape[1] * q_v.shape[2]
             d_prop = self.params["proprio_encoder.mlp.4.weight"].shape[0]
-            pos_t = torch.stack([ops.pos_emb_transpose(self.buffers[f"visual_extraction.{c}.pos_emb"].detach().float().to(device).contiguous(),
+            pos_t = torch.stack([ops.pos_emb_pack(self.buffers[f"visual_extraction.{c}.pos_emb"].detach().float().to(device).contiguous(),
                                                        clip_dtype) for c in range(cams)]).contiguous()
             pe = self.buffers["pe.pe"].detach()[0].float().to(device).contiguous()
             self._dims_cache = SimpleNamespace(d_text=d_text, d_vis=d_vis, d_prop=d_prop, f_t=d_text + cams * d_vis + d_prop, pos_t=pos_t, pe=pe)

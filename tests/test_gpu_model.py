@@ -170,7 +170,7 @@ def test_openclip_gelu_backbone_text_aware_extraction(dev):
     text = GI._tokens(rng, n_big, (3, 5, 8, 11, 17))                       # the 17-token prompt ends past the first 15 positions
     pos = sincos_position_embedding(256, 768)
     temp = torch.tensor([0.005])
-    pos_t = ops.pos_emb_transpose(pos.to(dev), torch.float16)[None].contiguous()
+    pos_t = ops.pos_emb_pack(pos.to(dev), torch.float16)[None].contiguous()
 
     def extract(n):
         tokens, p, d = clip.vision_tokens(images[:n].to(dev))

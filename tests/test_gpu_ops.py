@@ -245,7 +245,7 @@ def test_text_aware_pool(dev, n_obs, cams, P, D, K, t_rep, temperature, dtype):
     text = (_randn(25, n_obs // t_rep, K, D) * 0.3).to(dev)
     pos = torch.stack([R.sincos_position_embedding(P, D) * (1 + 0.1 * c) for c in range(cams)]).to(dev)
     temp = torch.full((cams,), temperature, device=dev)
-    pos_t = torch.stack([ops.pos_emb_transpose(pos[c], dt) for c in range(cams)])
+    pos_t = torch.stack([ops.pos_emb_pack(pos[c], dt) for c in range(cams)])
     out = ops.text_aware_pool(patches, text, pos_t, temp, n_obs, cams, t_rep)
     pf = patches.float().view(n_obs, cams, P, D)
     pf = pf / pf.norm(dim=-1, keepdim=True)

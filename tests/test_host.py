@@ -264,3 +264,55 @@ def test_flatten_parameters_aliases_the_module():
     flat.zero_()
     assert all(float(p.abs().sum()) == 0 for p in lin.parameters())
     assert bucket_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]
+
+
+# ------------------------------------------------------------------------------------- rollout loop and checkpoints
+def test_temporal_ensemble_and_receding_horizon_queue():
+    from otter_amd.rollout_server import ActionQueue, to_robot_action
+    a_dim = 10
+    chunks = [np.full((12, a_dim), 100.0 * s) + np.arange(12)[:, None] for s in range(5)]     # chunk s predicts value 100 s + t
+    q = ActionQueue(3, receding_horizon_control=False, k=0.05)
+    got = [q.next_action(c)[0] for c in chunks]
+    # step 0: only chunk 0 (t=0) -> 0.  step 1: chunk 0 (t=1) and chunk 1 (t=0), weights e^0, e^0.05.
+    w2 = np.exp(0.05 * np.arange(2)); w2 /= w2.sum()
+    w3 = np.exp(0.05 * np.arange(3)); w3 /= w3.sum()
+    assert got[0] == 0.0
+    assert abs(got[1] - (w2[0] * 1 + w2[1] * 100)) < 1e-12
+    assert abs(got[2] - (w3[0] * 2 + w3[1] * 101 + w3[2] * 200)) < 1e-12
+    # step 3: chunk 0 has been dropped (queue length 3); chunks 1, 2, 3 contribute their elements 2, 1, 0
+    assert abs(got[3] - (w3[0] * 102 + w3[1] * 201 + w3[2] * 300)) < 1e-12
+    r = ActionQueue(3, receding_horizon_control=True)
+    seq = []
+    for c in chunks:
+        assert r.needs_prediction() == (len(seq) % 3 == 0)
+        seq.append(r.next_action(c)[0])
+    assert seq == [0.0, 1.0, 2.0, 300.0, 301.0]                  # executes 3 actions of a chunk, then takes the newest chunk
+    act = np.array([0.1, 0.2, 0.3, 1, 0, 0, 0, 1, 0, 0.7])
+    out = to_robot_action(act)
+    assert out.shape == (7,) and np.allclose(out[:6], [0.1, 0.2, 0.3, 0, 0, 0]) and out[6] == 1.0
+    assert to_robot_action(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0.2]))[6] == 0.0
+    with pytest.raises(ValueError):
+        ActionQueue(0)
+
+
+def test_checkpoint_round_trip_in_reference_layout(tmp_path):
+    from otter_amd.checkpoint import load_checkpoint_state, save_checkpoint
+    from otter_amd.config import ExperimentConfig, ModelConfig, SharedConfig, load_run_yaml
+    from otter_amd.otter import OTTER
+    from otter_amd.otter_interface import load_state_dict_flexible
+    mc = ModelConfig(clip_model="tiny-test", transformer_dim=128, transformer_layers=2, transformer_heads=2, vision_pooling_output_dim=128,
+                     text_pooling_output_dim=64, proprio_hidden_dim=64, proprio_output_dim=32, pooling_heads=4)
+    sc = SharedConfig(image_size=112, seq_length=4, action_horizon=4)
+    args = ExperimentConfig(model_cfg=mc, shared_cfg=sc)
+    model = OTTER(mc, sc)
+    with torch.no_grad():
+        model.input_projection.bias.add_(1.5)
+    path = save_checkpoint(model, args, str(tmp_path), 7)
+    assert os.path.basename(path) == "checkpoint_7.pt" and os.path.exists(tmp_path / "run.yaml")
+    back = load_run_yaml(str(tmp_path / "run.yaml"))
+    assert back.model_cfg.clip_model == "tiny-test" and back.shared_cfg.seq_length == 4
+    fresh = OTTER(back.model_cfg, back.shared_cfg)
+    state = load_checkpoint_state(path)
+    load_state_dict_flexible(fresh, {"module." + k: v for k, v in state.items()})        # as saved from a DDP wrapper
+    for (n1, p1), (n2, p2) in zip(model.state_dict().items(), fresh.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1, p2)

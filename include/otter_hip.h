@@ -214,6 +214,15 @@ int otter_text_aware_pool_temperature_grad(int dtype, const void* patches, long 
                                            const float* temperature, const float* grad_out, float* partial, int n_obs, int cams,
                                            int P, int D, int K, int t_rep, void* stream);
 
+/* Centre-crop + bicubic resize of uint8 RGB frames, bit-identical to the host path crop2square + PIL
+ * Image.resize((S, S), BICUBIC) of otter_interface.py:98-108 / vision_tf.py:60-67.  src: [n][src_h][src_w][3];
+ * crop window (y0, x0, crop_h, crop_w); *_bounds: [S][2] (first source index, count), *_coef: [S][ksize] fixed-point
+ * weights (22 fractional bits) as PIL's precompute_coeffs / normalize_coeffs_8bpc produce them (host side:
+ * otter_amd.vision_tf.pil_bicubic_coeffs); tmp: [n][crop_h][S][3]; out: [n][3][S][S]. */
+int otter_resize_bicubic_u8(const unsigned char* src, int n, int src_h, int src_w, int y0, int x0, int crop_h, int crop_w,
+                            const int* h_bounds, const int* h_coef, int h_ksize, const int* v_bounds, const int* v_coef,
+                            int v_ksize, unsigned char* tmp, unsigned char* out, int out_size, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "otter_repeat_rows": [_P, _L, _P, _L, _I, _I, _I, _P],
     "otter_add_pe": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "otter_window_append": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "otter_resize_bicubic_u8": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     # training step
     "otter_sgemm_strided": [_P, _L, _L, _P, _L, _L, _P, _P, _L, _I, _I, _I, _I, _P],
     "otter_act_fwd": [_P, _P, _L, _I, _P],

@@ -240,3 +240,64 @@ extern "C" int otter_window_append(const float* src, const float* fresh, float* 
     OTTER_CHECK_LAUNCH("otter_window_append");
     return OTTER_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Centre-crop + bicubic resize of uint8 RGB camera frames, bit-identical to PIL's 8-bit resampler (what
+// otter_interface.py:98-108 does on the host with Image.resize(..., BICUBIC)): two separable passes, horizontal
+// first, each output = clip8((2^21 + sum_k coeff[k] * pixel[k]) >> 22) with the intermediate image rounded to
+// uint8.  The integer coefficient tables (22 fractional bits) come from the host, computed as PIL computes them.
+namespace {
+
+__device__ __forceinline__ unsigned char clip8_fixed(int acc) {
+    const int v = acc >> 22;                                  // arithmetic shift
+    return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// src: [n][src_h][src_w][3] interleaved, the crop starts at (y0, x0) and is crop_h x crop_w; tmp: [n][crop_h][S][3]
+__global__ void resize_h_kernel(const unsigned char* src, unsigned char* tmp, const int* bounds, const int* coef, int ksize,
+                                int n, int src_h, int src_w, int y0, int x0, int crop_h, int S) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n * crop_h * S * 3;
+    if (i >= total) return;
+    const int c = (int)(i % 3), xx = (int)((i / 3) % S), yy = (int)((i / (3L * S)) % crop_h), img = (int)(i / (3L * S * crop_h));
+    const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+    const unsigned char* row = src + (((long)img * src_h + y0 + yy) * src_w + x0 + xmin) * 3 + c;
+    int acc = 1 << 21;
+    for (int k = 0; k < cnt; ++k) acc += (int)row[3 * k] * coef[xx * ksize + k];
+    tmp[i] = clip8_fixed(acc);
+}
+
+// tmp: [n][crop_h][S][3] -> out: [n][3][S][S] planar (the layout the patch-extraction kernel reads)
+__global__ void resize_v_kernel(const unsigned char* tmp, unsigned char* out, const int* bounds, const int* coef, int ksize,
+                                int n, int crop_h, int S) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n * 3 * S * S;
+    if (i >= total) return;
+    const int xx = (int)(i % S), yy = (int)((i / S) % S), c = (int)((i / ((long)S * S)) % 3), img = (int)(i / (3L * S * S));
+    const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+    const unsigned char* col = tmp + (((long)img * crop_h + ymin) * S + xx) * 3 + c;
+    int acc = 1 << 21;
+    for (int k = 0; k < cnt; ++k) acc += (int)col[(long)k * S * 3] * coef[yy * ksize + k];
+    out[i] = clip8_fixed(acc);
+}
+
+}  // namespace
+
+extern "C" int otter_resize_bicubic_u8(const unsigned char* src, int n, int src_h, int src_w, int y0, int x0, int crop_h, int crop_w,
+                                       const int* h_bounds, const int* h_coef, int h_ksize, const int* v_bounds, const int* v_coef,
+                                       int v_ksize, unsigned char* tmp, unsigned char* out, int out_size, void* stream) {
+    OTTER_REQUIRE(src && h_bounds && h_coef && v_bounds && v_coef && tmp && out, OTTER_ERR_INVALID_ARGUMENT, "otter_resize_bicubic_u8: null operand");
+    if (n == 0) return OTTER_OK;
+    OTTER_REQUIRE(n > 0 && out_size > 0 && crop_h > 0 && crop_w > 0 && y0 >= 0 && x0 >= 0 && y0 + crop_h <= src_h && x0 + crop_w <= src_w &&
+                  h_ksize > 0 && v_ksize > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_resize_bicubic_u8: crop (%d,%d)+(%d,%d) outside %dx%d or bad sizes",
+                  y0, x0, crop_h, crop_w, src_h, src_w);
+    hipStream_t s = (hipStream_t)stream;
+    const long th = (long)n * crop_h * out_size * 3, tv = (long)n * 3 * out_size * out_size;
+    OTTER_REQUIRE((th + 255) / 256 < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_resize_bicubic_u8: batch too large");
+    hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, src, tmp, h_bounds, h_coef, h_ksize, n, src_h, src_w,
+                       y0, x0, crop_h, out_size);
+    OTTER_CHECK_LAUNCH("otter_resize_bicubic_u8 (horizontal)");
+    hipLaunchKernelGGL(resize_v_kernel, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, s, tmp, out, v_bounds, v_coef, v_ksize, n, crop_h, out_size);
+    OTTER_CHECK_LAUNCH("otter_resize_bicubic_u8 (vertical)");
+    return OTTER_OK;
+}

@@ -19,7 +19,7 @@ from .action_utils import convert_abs_action
 from .config import ExperimentConfig, load_run_yaml
 from .otter import OTTER, create_text_mask
 from .tokenizer import tokenize
-from .vision_tf import crop2square, pil_to_uint8_chw
+from .vision_tf import crop2square, crop_resize_device, pil_to_uint8_chw
 
 
 def load_state_dict_flexible(model, state_dict):
@@ -74,11 +74,20 @@ class OtterInference(_InferenceBase):
         return torch.tensor(data).float()
 
     def _preprocess_images(self, images: Dict[str, Image.Image]) -> torch.Tensor:
-        """Centre-crop, bicubic resize to image_size (``otter_interface.py:86-111``) -> uint8 (cams, 3, S, S)."""
+        """Centre-crop, bicubic resize to image_size (``otter_interface.py:86-111``) -> uint8 (cams, 3, S, S).
+
+        The raw frames are uploaded and cropped / resized on the GPU by a kernel pair that reproduces PIL's 8-bit bicubic
+        resampler bit for bit; on a CPU-resident model the host does it with PIL as upstream."""
         assert set(images.keys()) == set(self.model.camera_keys)
         size = self.args.shared_cfg.image_size
-        out = [pil_to_uint8_chw(crop2square(images[k]).resize((size, size), Image.Resampling.BICUBIC))
-               for k in self.model.camera_keys]
+        device = self.model.input_projection.weight.device
+        if device.type != "cuda":
+            return torch.stack([pil_to_uint8_chw(crop2square(images[k]).resize((size, size), Image.Resampling.BICUBIC))
+                                for k in self.model.camera_keys], dim=0)
+        out = []
+        for k in self.model.camera_keys:
+            frame = torch.from_numpy(np.asarray(images[k].convert("RGB"), dtype=np.uint8).copy())
+            out.append(crop_resize_device(frame[None].to(device), size)[0])
         return torch.stack(out, dim=0)
 
     def _decode_actions(self, actions: Union[np.ndarray, torch.Tensor]) -> np.ndarray:

@@ -227,3 +227,75 @@ def test_long_history_rollout_64_episodes_window_32(dev):
             worst = max(worst, (got[e] - ref).abs().max().item())
     print(f"64 episodes x window 32: max |action - oracle| over {steps} steps = {worst:.2e}")
     assert worst <= 1e-3
+
+
+def _write_synthetic_merges(path, n=49152 - 256 - 2):
+    """A merges file with the real file's shape (header + 48894 pairs, so start/end-of-text get ids 49406 / 49407) but made-up
+    pairs: the real vocabulary is not redistributed.  The first pairs are real English merges so prompts shorten a little."""
+    from otter_amd.tokenizer import bytes_to_unicode
+    base = list(bytes_to_unicode().values())
+    syms = base + [b + "</w>" for b in base]
+    pairs = [("t", "h"), ("th", "e</w>"), ("p", "i"), ("pi", "c"), ("pic", "k</w>"), ("u", "p</w>"), ("c", "u"), ("b", "e</w>"), ("cu", "be</w>")]
+    seen = set(pairs)
+    i = 0
+    while len(pairs) < n:
+        a, b = syms[100 + (i // 400) % 400], syms[101 + i % 400]      # 160,000 candidate pairs of mostly non-ASCII symbols
+        i += 1
+        if (a, b) not in seen:
+            seen.add((a, b))
+            pairs.append((a, b))
+    with open(path, "w", encoding="utf-8") as fh:
+        fh.write("#version: synthetic\n")
+        fh.write("\n".join(f"{a} {b}" for a, b in pairs) + "\n")
+
+
+def test_otter_inference_end_to_end(dev, tmp_path, monkeypatch):
+    """The rollout interface as a robot script uses it: checkpoint folder on disk -> OtterInference -> PIL frames, prompt,
+    pose and gripper in -> absolute action chunk out; six calls across the window boundary against the CPU oracle fed
+    with PIL-resized frames; then reset()."""
+    from PIL import Image
+    from otter_amd import tokenizer as tk
+    from otter_amd.action_utils import convert_abs_action
+    from otter_amd.checkpoint import save_checkpoint
+    from otter_amd.config import ExperimentConfig
+    from otter_amd.otter_interface import OtterInference
+    from otter_amd.vision_tf import crop2square, pil_to_uint8_chw
+    from scipy.spatial.transform import Rotation
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], torch.device("cpu"))
+    save_checkpoint(model, ExperimentConfig(model_cfg=mc, shared_cfg=sc), str(tmp_path), 3)
+    bpe = tmp_path / "merges.txt"
+    _write_synthetic_merges(str(bpe))
+    monkeypatch.setenv("OTTER_CLIP_BPE", str(bpe))
+    monkeypatch.setattr(tk, "_default", None)
+    policy = OtterInference(str(tmp_path), 3, device="cuda")
+    assert sorted(policy.model.camera_keys) == policy.model.camera_keys and policy.current_proprio is None
+    prompt = "pick up the cube"
+    ids = tk.tokenize([prompt])[0]
+    assert ids[0] == 49406 and int(ids.max()) == 49407 and int((ids != 0).sum()) == 6        # SOT pick up the cube EOT
+    rng = np.random.default_rng(3)
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length)
+    ro = R.Rollout(sd, dims)
+    worst = 0.0
+    for step in range(sc.seq_length + 2):
+        frames = {k: Image.fromarray(rng.integers(0, 256, (180, 320, 3), dtype=np.uint8)) for k in policy.model.camera_keys}
+        pose = rng.standard_normal(6) * 0.3
+        grip = rng.uniform(-0.2, 1.2, 1)
+        got = policy(frames, prompt, pose, grip)
+        assert got.shape == (sc.action_horizon, mc.action_dim)
+        rot = Rotation.from_euler("XYZ", pose[3:]).as_matrix()[:2].reshape(6)
+        prop = np.concatenate([pose[:3], rot, np.clip(grip, 0, 1)])
+        np.testing.assert_allclose(policy.current_proprio, prop, rtol=0, atol=1e-12)
+        imgs = torch.stack([pil_to_uint8_chw(crop2square(frames[k]).resize((sc.image_size, sc.image_size), Image.Resampling.BICUBIC))
+                            for k in policy.model.camera_keys])
+        ref = ro.step(R.clip_transform(imgs), ids, torch.tensor(prop).float()).numpy()
+        ref_abs = convert_abs_action(ref[None].astype(np.float64), prop[None, None])[0]
+        worst = max(worst, float(np.abs(got - ref_abs).max()))
+    print(f"OtterInference end to end: max |absolute action - oracle| = {worst:.2e}")
+    assert worst <= 1e-3
+    policy.reset()
+    assert policy.current_proprio is None and policy.model.cache_size == 0
+    with pytest.raises(AssertionError):
+        policy({"image_primary": frames["image_primary"]}, prompt, pose, grip)              # a camera is missing

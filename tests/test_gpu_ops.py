@@ -327,3 +327,18 @@ def test_window_append_matches_reference_cache(dev):
             assert n == len(hist[b])
             assert torch.equal(bufs[cur][b, :n].cpu(), torch.stack(hist[b]))
             assert torch.all(bufs[cur][b, n:] == 0)
+
+
+@pytest.mark.parametrize("h,w,size", [(180, 320, 224), (720, 1280, 224), (300, 200, 224), (224, 224, 224)])
+def test_crop_resize_device_is_pil_bicubic_bit_for_bit(dev, h, w, size):
+    from PIL import Image
+    from otter_amd.vision_tf import crop2square, crop_resize_device, pil_to_uint8_chw
+    rng = np.random.default_rng(h + 3 * w)
+    frames = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+    frames[1, : h // 2] = 255
+    got = crop_resize_device(torch.from_numpy(frames).to(dev), size).cpu().numpy()
+    for i in range(3):
+        want = pil_to_uint8_chw(crop2square(Image.fromarray(frames[i])).resize((size, size), Image.Resampling.BICUBIC)).numpy()
+        assert np.array_equal(got[i], want)
+    with pytest.raises(ValueError):
+        crop_resize_device(torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device=dev), size)

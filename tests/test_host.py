@@ -316,3 +316,17 @@ def test_checkpoint_round_trip_in_reference_layout(tmp_path):
     load_state_dict_flexible(fresh, {"module." + k: v for k, v in state.items()})        # as saved from a DDP wrapper
     for (n1, p1), (n2, p2) in zip(model.state_dict().items(), fresh.state_dict().items()):
         assert n1 == n2 and torch.equal(p1, p2)
+
+
+@pytest.mark.parametrize("h,w,size", [(180, 320, 224), (720, 1280, 224), (300, 200, 224), (224, 224, 224), (512, 512, 112)])
+def test_resize_arithmetic_is_pil_bicubic_bit_for_bit(h, w, size):
+    """The fixed-point tables and two-pass arithmetic the GPU resize kernel uses, against PIL itself (down-scaling with
+    antialiasing, up-scaling, landscape and portrait crops)."""
+    from PIL import Image
+    from otter_amd.vision_tf import crop2square, crop_resize_reference_arithmetic, pil_to_uint8_chw
+    rng = np.random.default_rng(h * 7 + w)
+    frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    frame[: h // 3] = (frame[: h // 3] // 64) * 64                      # flat regions and hard edges as well as noise
+    want = pil_to_uint8_chw(crop2square(Image.fromarray(frame)).resize((size, size), Image.Resampling.BICUBIC)).numpy()
+    got = crop_resize_reference_arithmetic(frame, size)
+    assert got.shape == want.shape and np.array_equal(got, want)

@@ -210,11 +210,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
+    # One process per GPU.  OTTER_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks
+    # share the visible devices and synchronise through the host (RCCL refuses two ranks on one device).
+    backend = os.environ.get("OTTER_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+    sync_device = device if backend == "nccl" else torch.device("cpu")
 
     clip_dtype = torch.float16 if args.clip_dtype == "f16" else torch.bfloat16
     work = Workload(device, seed=rank, clip_dtype=clip_dtype) if args.workload == "infer" else TrainWorkload(device, seed=rank, clip_dtype=clip_dtype)
@@ -223,7 +228,7 @@ def main():
         work.step()
     work.t = 0                                           # timed region starts at an episode boundary
     # barrier + device sync on both sides of exactly `steps` steps; MAX over ranks
-    elapsed = timed_region(work.step, args.steps, world=world, sync=torch.cuda.synchronize, device=device)
+    elapsed = timed_region(work.step, args.steps, world=world, sync=torch.cuda.synchronize, device=sync_device)
 
     result = None
     if rank == 0:

@@ -12,7 +12,8 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------------------------
 // C[M,N] (+)= op(A)[M,K] . op(B)[K,N] (+ bias[n]),  A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn].
-// One workgroup = 64x64 output tile, 4 waves of 32x32 (2x2 v_mfma_f32_16x16x4_f32 tiles), K-step 16 through LDS.
+// One workgroup = 64x64 output tile, 4 waves of 32x32 (2x2 v_mfma_f32_16x16x4_f32 tiles), K-step 32 through LDS with the
+// next step's operands prefetched into registers.
 // Used for the forward (x W^T), the input gradient (dy W) and the weight gradient (dy^T x) of every linear layer,
 // straight from the parameter storage (no packed copies to refresh after an optimizer step).
 struct SGemm {
@@ -23,7 +24,8 @@ struct SGemm {
     int M, N, K, accumulate;
 };
 
-constexpr int SG_T = 64, SG_K = 16, SG_LD = SG_T + 4;
+constexpr int SG_T = 64, SG_K = 32, SG_LD = SG_T + 4;
+constexpr int SG_E = SG_T * SG_K / 256;            // elements of each operand tile per thread and K-step
 
 __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
     __shared__ float As[SG_K][SG_LD];     // [k][m]
@@ -40,26 +42,33 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < p.K; k0 += SG_K) {
-        float av[4], bv[4];
+    // element e of a tile: the thread order follows whichever index is contiguous in memory
+    auto a_idx = [&](int e, int& k, int& m) { if (a_kfast) { k = e % SG_K; m = e / SG_K; } else { m = e % SG_T; k = e / SG_T; } };
+    auto b_idx = [&](int e, int& k, int& n) { if (b_nfast) { n = e % SG_T; k = e / SG_T; } else { k = e % SG_K; n = e / SG_K; } };
+    float av[SG_E], bv[SG_E];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + 256 * i;
-            const int ak = a_kfast ? (e & 15) : (e >> 6), am = a_kfast ? (e >> 4) : (e & 63);
-            const int bn = b_nfast ? (e & 63) : (e >> 4), bk = b_nfast ? (e >> 6) : (e & 15);
-            av[i] = (m0 + am < p.M && k0 + ak < p.K) ? p.A[(long)(m0 + am) * p.sam + (long)(k0 + ak) * p.sak] : 0.f;
-            bv[i] = (n0 + bn < p.N && k0 + bk < p.K) ? p.B[(long)(k0 + bk) * p.sbk + (long)(n0 + bn) * p.sbn] : 0.f;
+        for (int i = 0; i < SG_E; ++i) {
+            int k, m, n, kb;
+            a_idx(tid + 256 * i, k, m);
+            b_idx(tid + 256 * i, kb, n);
+            av[i] = (m0 + m < p.M && k0 + k < p.K) ? p.A[(long)(m0 + m) * p.sam + (long)(k0 + k) * p.sak] : 0.f;
+            bv[i] = (n0 + n < p.N && k0 + kb < p.K) ? p.B[(long)(k0 + kb) * p.sbk + (long)(n0 + n) * p.sbn] : 0.f;
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < p.K; k0 += SG_K) {
         __syncthreads();                  // previous K-step's fragments have been read
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + 256 * i;
-            const int ak = a_kfast ? (e & 15) : (e >> 6), am = a_kfast ? (e >> 4) : (e & 63);
-            const int bn = b_nfast ? (e & 63) : (e >> 4), bk = b_nfast ? (e >> 6) : (e & 15);
-            As[ak][am] = av[i];
-            Bs[bk][bn] = bv[i];
+        for (int i = 0; i < SG_E; ++i) {
+            int k, m, n, kb;
+            a_idx(tid + 256 * i, k, m);
+            b_idx(tid + 256 * i, kb, n);
+            As[k][m] = av[i];
+            Bs[kb][n] = bv[i];
         }
         __syncthreads();
+        if (k0 + SG_K < p.K) fetch(k0 + SG_K);            // the next tile's loads are in flight under this step's MFMAs
 #pragma unroll
         for (int kk = 0; kk < SG_K / 4; ++kk) {
             float a[2], b[2];
@@ -125,15 +134,19 @@ __global__ void act_bwd_kernel(const float* z, const float* dy, float* dz, long 
 // out[c] (+)= sum_r x[r*ld + c] * (y ? y[r*ldy + c] : 1):   bias gradients, broadcast-parameter gradients
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* x, long ldx, const float* y, long ldy, int rows, int cols,
                                                       float* out, int accumulate) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    // a workgroup owns 16 columns: 16 row groups x 16 columns, combined through LDS in a fixed order
+    __shared__ float part[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (c < cols)
-        for (int r = rg; r < rows; r += 4) s += x[(long)r * ldx + c] * (y ? y[(long)r * ldy + c] : 1.0f);
-    part[rg][threadIdx.x & 63] = s;
+        for (int r = rg; r < rows; r += 16) s += x[(long)r * ldx + c] * (y ? y[(long)r * ldy + c] : 1.0f);
+    part[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && c < cols) {
-        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][cl];
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -175,22 +188,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, long ldx, c
 // dgamma[c] += sum_r dy * xh ; dbeta[c] += sum_r dy
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* x, long ldx, const float* dy, long ldy, const float* stats,
                                                             int rows, int width, float* dgamma, float* dbeta) {
-    __shared__ float pg[4][64], pb[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    __shared__ float pg[16][17], pb[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float sg = 0.f, sb = 0.f;
     if (c < width)
-        for (int r = rg; r < rows; r += 4) {
+        for (int r = rg; r < rows; r += 16) {
             const float d = dy[(long)r * ldy + c];
             sg += d * (x[(long)r * ldx + c] - stats[2 * r]) * stats[2 * r + 1];
             sb += d;
         }
-    pg[rg][threadIdx.x & 63] = sg;
-    pb[rg][threadIdx.x & 63] = sb;
+    pg[rg][cl] = sg;
+    pb[rg][cl] = sb;
     __syncthreads();
     if (rg == 0 && c < width) {
-        const int t = threadIdx.x;
-        dgamma[c] += (pg[0][t] + pg[1][t]) + (pg[2][t] + pg[3][t]);
-        dbeta[c] += (pb[0][t] + pb[1][t]) + (pb[2][t] + pb[3][t]);
+        float tg = 0.f, tb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { tg += pg[i][cl]; tb += pb[i][cl]; }
+        dgamma[c] += tg;
+        dbeta[c] += tb;
     }
 }
 
@@ -415,19 +431,34 @@ __global__ __launch_bounds__(256) void tave_temp_grad_kernel(TaveGrad p) {
     __syncthreads();
     const T* X = (const T*)p.patches + (long)unit * p.unit_stride;
     const float* pos = p.pos + (long)cam * P * D;
+    constexpr int MAXE = 16;                                   // D <= 1024: at most 16 elements of a row per lane
+    const int ne = D / 64;
     for (int pp = wave; pp < P; pp += 4) {
+        float xv[MAXE], pv[MAXE];
         float sq = 0.f;
-        for (int i = lane; i < D; i += 64) { const float x = (float)X[(long)pp * D + i]; sq += x * x; }
-        const float rn = 1.0f / sqrtf(wave_sum(sq));
-        for (int k = 0; k < K; ++k) {
-            float s = 0.f, c = 0.f;
-            for (int i = lane; i < D; i += 64) {
-                const float xh = (float)X[(long)pp * D + i] * rn;
-                s += xh * th[k * D + i];
-                c += (xh + pos[(long)pp * D + i]) * gs[k * D + i];
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            xv[e] = pv[e] = 0.f;
+            if (e < ne) {
+                xv[e] = (float)X[(long)pp * D + e * 64 + lane];
+                pv[e] = pos[(long)pp * D + e * 64 + lane];
+                sq += xv[e] * xv[e];
             }
-            s = wave_sum(s); c = wave_sum(c);
-            if (lane == 0) { sv[k * P + pp] = s; cv[k * P + pp] = c; }
+        }
+        const float rn = 1.0f / sqrtf(wave_sum(sq));
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) { xv[e] *= rn; pv[e] += xv[e]; }          // xh and v = xh + pos
+        for (int k = 0; k < K; ++k) {
+            float sk = 0.f, ck = 0.f;
+#pragma unroll
+            for (int e = 0; e < MAXE; ++e)
+                if (e < ne) {
+                    sk += xv[e] * th[k * D + e * 64 + lane];
+                    ck += pv[e] * gs[k * D + e * 64 + lane];
+                }
+            sk = wave_sum(sk);
+            ck = wave_sum(ck);
+            if (lane == 0) { sv[k * P + pp] = sk; cv[k * P + pp] = ck; }
         }
     }
     __syncthreads();
@@ -491,7 +522,7 @@ extern "C" int otter_act_bwd(const float* z, const float* dy, float* dz, long n,
 
 extern "C" int otter_col_sum(const float* x, long ldx, const float* y, long ldy, int rows, int cols, float* out, int accumulate, void* stream) {
     OTTER_REQUIRE(x && out && rows >= 0 && cols > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_col_sum: bad arguments");
-    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols, out, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols, out, accumulate ? 1 : 0);
     OTTER_CHECK_LAUNCH("otter_col_sum");
     return OTTER_OK;
 }
@@ -506,7 +537,7 @@ extern "C" int otter_layernorm_bwd(const float* x, long ldx, const float* gamma,
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, gamma, dy, ldy, dx, lddx, stats, rows, width, eps);
     OTTER_CHECK_LAUNCH("otter_layernorm_bwd");
     if (dgamma) {
-        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((width + 63) / 64), dim3(256), 0, s, x, ldx, dy, ldy, stats, rows, width, dgamma, dbeta);
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((width + 15) / 16), dim3(256), 0, s, x, ldx, dy, ldy, stats, rows, width, dgamma, dbeta);
         OTTER_CHECK_LAUNCH("otter_layernorm_bwd (parameters)");
     }
     return OTTER_OK;
@@ -603,6 +634,7 @@ extern "C" int otter_text_aware_pool_temperature_grad(int dtype, const void* pat
     if (n_obs == 0) return OTTER_OK;
     OTTER_REQUIRE(n_obs > 0 && cams > 0 && t_rep > 0 && n_obs % t_rep == 0 && P > 0 && D > 0 && K > 0, OTTER_ERR_INVALID_ARGUMENT,
                   "otter_text_aware_pool_temperature_grad: bad sizes");
+    OTTER_REQUIRE(D % 64 == 0 && D <= 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_temperature_grad: D=%d must be a multiple of 64, at most 1024", D);
     const size_t lds = sizeof(float) * ((size_t)2 * K * D + (size_t)2 * K * P + K);
     OTTER_REQUIRE(lds <= 160 * 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_temperature_grad: needs %zu bytes of LDS", lds);
     TaveGrad a{patches, unit_stride, dtype == DT_F16, text, pos, temperature, grad_out, partial, cams, P, D, K, t_rep, n_obs};

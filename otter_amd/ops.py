@@ -133,6 +133,8 @@ def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], *, eps
     ro, wo, ldy = _rows_view(out, "layernorm.out")
     if ro != rows or wo != width:
         raise ValueError("layernorm: out shape mismatch")
+    if rows == 0:
+        return out
     _lib.call("otter_layernorm", _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(out), ldy, rows, width, eps, dt, _stream())
     return out
 
@@ -200,6 +202,8 @@ def attn_d64(qkv: Tensor, n_seq: int, seq_len: int, heads: int, causal: bool) ->
     if rows != n_seq * seq_len or width != 3 * heads * 64:
         raise ValueError(f"attn: qkv {tuple(qkv.shape)} does not match n_seq={n_seq} L={seq_len} heads={heads}")
     out = torch.empty(rows, heads * 64, dtype=qkv.dtype, device=qkv.device)
+    if rows == 0:
+        return out
     _lib.call("otter_attn_fwd_d64", dt, _ptr(qkv), ld, _ptr(out), heads * 64, n_seq, seq_len, heads, int(causal), _stream())
     return out
 
@@ -256,6 +260,8 @@ def text_aware_pool(patches: Tensor, text: Tensor, pos_packed: Tensor, temperatu
         if not t.is_contiguous():
             raise ValueError("tave: operands must be contiguous")
     out = torch.empty(cams, n_obs, k, d, dtype=torch.float32, device=patches.device)
+    if n_obs == 0:
+        return out
     base = ctypes.c_void_p(patches.data_ptr() + (rows - p) * d * 2)
     _lib.call("otter_text_aware_pool_fwd", dt, base, rows * d, _ptr(text), _ptr(pos_packed), _ptr(temperature), _ptr(out),
               n_obs, cams, p, d, k, t_rep, _stream())

@@ -299,3 +299,29 @@ def test_otter_inference_end_to_end(dev, tmp_path, monkeypatch):
     assert policy.current_proprio is None and policy.model.cache_size == 0
     with pytest.raises(AssertionError):
         policy({"image_primary": frames["image_primary"]}, prompt, pose, grip)              # a camera is missing
+
+
+def test_bf16_towers_and_batch_independence(dev):
+    """bfloat16 operands for the towers (the alternative to the fp16 default): visual tokens still reach cosine 0.9999
+    against the fp32 oracle; actions carry bf16's 8x larger rounding (documented bound 4e-3, the fp16 default is held
+    to 1e-3 above).  Also: an observation's result does not depend on the batch it is computed in (bit for bit)."""
+    from otter_amd.config import ModelConfig, SharedConfig
+    mc, sc = ModelConfig(), SharedConfig()
+    model, sd = _model(mc, sc, 0, dev)
+    model.clip_compute_dtype = torch.bfloat16
+    rng = np.random.default_rng(8)
+    images = torch.from_numpy(rng.integers(0, 256, (4, 1, 2, 3, 224, 224), dtype=np.uint8))
+    text = GI._tokens(rng, 4, (5, 9))
+    proprio = torch.from_numpy(rng.standard_normal((4, 1, 10)).astype(np.float32))
+    pf, tf = model.extract_clip_features(images[:1].to(dev), text[:1])
+    with torch.no_grad():
+        ref_pf = clip_ref.patch_features(R.clip_transform(images[0, 0]), sd)
+    assert min(_cos(pf[c][0].cpu(), ref_pf[c]) for c in range(2)) >= 0.9999
+    acts = model(images.to(dev), text, proprio.to(dev)).cpu()
+    with torch.no_grad():
+        ref = R.forward(images[:1], text[:1], proprio[:1], sd, R.Dims())
+    err = (acts[:1] - ref).abs().max().item()
+    print(f"bf16 towers: max |action - oracle| = {err:.2e}")
+    assert err <= 4e-3
+    alone = model(images[2:3].to(dev), text[2:3], proprio[2:3].to(dev)).cpu()
+    assert torch.equal(alone[0], acts[2])

@@ -342,3 +342,48 @@ def test_crop_resize_device_is_pil_bicubic_bit_for_bit(dev, h, w, size):
         assert np.array_equal(got[i], want)
     with pytest.raises(ValueError):
         crop_resize_device(torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device=dev), size)
+
+
+def test_empty_and_limit_cases(dev):
+    """Zero-sized problems are no-ops; sizes past a kernel's limit are refused with an error, never run."""
+    from otter_amd import ops
+    f16 = torch.float16
+    w = ops.pack_weight(torch.randn(64, 64), f16, dev)
+    assert ops.gemm(torch.zeros(0, 64, dtype=f16, device=dev), w, 64).shape == (0, 64)
+    ops.layernorm(torch.zeros(0, 64, device=dev), torch.ones(64, device=dev), torch.zeros(64, device=dev), out_dtype=f16)
+    assert ops.attn_d64(torch.zeros(0, 3 * 64, dtype=f16, device=dev), 0, 7, 1, False).shape[0] == 0
+    with pytest.raises(ops.OtterHipError):
+        ops.attn_d64(torch.zeros(289, 3 * 64, dtype=f16, device=dev), 1, 289, 1, False)          # more than 288 keys
+    kv = torch.zeros(1, 65, 3 * 64, device=dev)
+    with pytest.raises(ops.OtterHipError):
+        ops.attn_policy(kv, 1, 0, 1)                                                              # window > 64
+    with pytest.raises(ops.OtterHipError):
+        ops.small_attn_fwd(torch.zeros(1, 33, 8, device=dev), torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 4, 8, device=dev), 1, False)
+    pos = ops.pos_emb_pack(torch.zeros(16, 128, device=dev), f16)[None].contiguous()
+    out = ops.text_aware_pool(torch.zeros(0, 16, 128, dtype=f16, device=dev), torch.zeros(0, 3, 128, device=dev), pos,
+                              torch.ones(1, device=dev), 0, 1, 1)
+    assert out.shape == (1, 0, 3, 128)
+    with pytest.raises(ops.OtterHipError):
+        ops.text_aware_pool(torch.zeros(1, 16, 128, dtype=f16, device=dev), torch.zeros(1, 17, 128, device=dev), pos,
+                            torch.ones(1, device=dev), 1, 1, 1)                                    # more than 16 text tokens
+
+
+def test_text_aware_pool_convexity_at_bench_size(dev):
+    """Size-independent property at the benchmark's launch size (128 units, 256 patches, 768 wide): with a constant
+    positional table c the output is c plus a convex combination of unit vectors, so |out - c| <= 1, and a unit whose
+    patches are all equal returns exactly that direction whatever the text is."""
+    from otter_amd import ops
+    n_obs, cams, P, D, K = 64, 2, 256, 768, 15
+    g = torch.Generator().manual_seed(5)
+    patches = torch.randn(n_obs * cams, P, D, generator=g)
+    patches[7] = patches[7, :1].expand(P, D)                      # unit 7: identical patches
+    text = torch.randn(n_obs, K, D, generator=g)
+    c = torch.randn(D, generator=g) * 0.3
+    pos = torch.stack([ops.pos_emb_pack(c.expand(P, D).contiguous().to(dev), torch.float16)] * cams)
+    out = ops.text_aware_pool(patches.to(dev).half(), text.to(dev), pos, torch.tensor([0.07, 0.02], device=dev), n_obs, cams, 1)
+    centred = out.cpu() - c.half().float()
+    assert float(centred.norm(dim=-1).max()) <= 1.0 + 5e-3
+    m, cam = 7 // cams, 7 % cams
+    direction = patches[7, 0].half().float()
+    direction = direction / direction.norm()
+    torch.testing.assert_close(centred[cam, m], direction.expand(K, D), rtol=0, atol=3e-3)

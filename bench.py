@@ -251,15 +251,16 @@ def main():
             gm = k["gemm"]
             # dominant kernel: the bf16 MFMA GEMM (CLIP tower launches are >99.9% of its FLOPs)
             tf = gm["total_work"] / (gm["total_ms"] * 1e-3) / 1e12
-            traffic = None                      # HBM-side bytes per launch from the PMC passes of this same command (profiles/)
+            traffic = mfma_busy = None          # from the PMC passes of this same command (profiles/): bytes per launch, MFMA-busy share
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as fh:
-                    traffic = json.load(fh)["traffic_bytes_per_launch"]
+                    pmc = json.load(fh)
+                traffic, mfma_busy = pmc["traffic_bytes_per_launch"], pmc.get("mfma_busy_fraction_of_simd_cycles")
             except (OSError, KeyError, ValueError):
                 pass
             result["roofline"] = {"bound": "mfma", "kernel": "gemm_256x256 (16-bit operands, CLIP towers; whole 256-row tiles)", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
                                   "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": traffic,
-                                  "algorithmic_bytes_per_launch": gm["total_bytes"] / gm["launches"],
+                                  "algorithmic_bytes_per_launch": gm["total_bytes"] / gm["launches"], "pmc_mfma_busy_frac": mfma_busy,
                                   "launches": gm["launches"], "avg_launch_us": 1e3 * gm["total_ms"] / gm["launches"],
                                   "gemm_ms_per_step": gm["total_ms"] / 2}
             tv = k["tave"]

@@ -5,13 +5,14 @@
 //   A    = softmax_over_patches(S / clamp(temperature, 0, 100))
 //   out  = A . (X^ + pos_emb)     (K x D, fp32)
 //
-// One workgroup (4 waves) per unit, one workgroup per CU.  The patch tokens stream HBM -> LDS exactly once, in
-// 16-patch tiles by LDS-DMA (global_load_lds_dwordx4) through three buffers, so two tiles are in flight behind
-// the one being consumed and the only wait per tile is a counted s_waitcnt.  Per tile:
+// One workgroup (4 waves) per unit; LDS and registers are budgeted so that two workgroups share a CU and overlap each
+// other's dependent chains.  The patch tokens stream HBM -> LDS exactly once, in 16-patch tiles by LDS-DMA
+// (global_load_lds_dwordx4) through two buffers, so one tile is in flight behind the one being consumed and the only
+// wait per tile is an s_waitcnt.  Per tile:
 //   * S^T tile (patch x text) and the Gram diagonal |x|^2 come from v_mfma_f32_16x16x32 over D; each wave
-//     reduces its quarter of D and the four partial tiles are summed through LDS (identical softmax state in
-//     all waves afterwards);
-//   * online softmax over patches (running max / sum per text token, one text token per lane);
+//     reduces its quarter of D (its text fragments stay in registers for the whole unit) and the four partial
+//     tiles are summed through LDS (identical softmax state in all waves afterwards);
+//   * online softmax over patches (running max / sum per text token, one text token per lane), in log2 units;
 //   * O^T += X^T . (p/|x|)  +  pos^T . p   with v_mfma_f32_16x16x16: the S^T accumulator layout
 //     (patch 4g+r on the registers, text token on the lane) is exactly that instruction's B operand, X^T comes
 //     from the row-major LDS tile by ds_read_b64_tr_b16, and pos^T comes from a 16-bit copy of pos_emb packed in
@@ -44,21 +45,26 @@ __device__ __forceinline__ int f_swz(int r) {
     return (((lo + 4 * hi) & 7) << 1) | hi;
 }
 
-template <typename T, int NDT>   // D = NDT * 64; each wave owns NDT d-tiles of 16 columns
-__global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
+// NW waves per workgroup: each reduces D/NW columns of the similarity product and owns D/NW output columns (NDTW d-tiles
+// of 16).  NST = patch-tile buffers in LDS (prefetch distance NST-1 tiles).  WGS = workgroups the register budget lets
+// share a CU: the waves of co-resident workgroups overlap each other's dependent chains.
+template <typename T, int D, int NW, int NST, int WGS>
+__global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 v8;
     typedef typename Half16<T>::v4 v4;
-    constexpr int D = NDT * 64;
+    constexpr int NDTW = D / 16 / NW;           // d-tiles per wave
     constexpr int ROWB = D * 2;                 // bytes per LDS row
     constexpr int TILE_B = 16 * ROWB;           // one 16-row image
     constexpr int CPR = D / 8;                  // 16-byte chunks per row
-    constexpr int NLD = TILE_B / (256 * 16);    // LDS-DMA instructions per thread per tile
-    constexpr int NST = 3;                      // patch-tile stages: two tiles in flight behind the one being consumed
-    constexpr int KSW = D / 32 / 4;             // K-steps (32 columns) of the similarity product per wave
-    char* sT = smem;
-    char* sX = smem + TILE_B;
-    float* sP = (float*)(smem + (1 + NST) * TILE_B);       // [2][4 waves][64 lanes][8]: partial S^T and Gram tiles
+    constexpr int NLD = TILE_B / (NW * 64 * 16);// LDS-DMA instructions per thread per tile
+    constexpr int PF = NST - 1;                 // prefetch distance in tiles
+    constexpr int KSW = D / 32 / NW;            // K-steps (32 columns) of the similarity product per wave
+    constexpr int TRW = 16 / NW;                // text rows normalised per wave
+    static_assert(NDTW >= 2 && NDTW % 2 == 0 && KSW >= 1 && NLD >= 1 && NST >= 2, "unsupported D / wave count");
+    char* sX = smem;
+    char* sT = smem + (NST - 1) * TILE_B;       // text image: borrows the buffer that the first prefetch fills last
+    float* sP = (float*)(smem + NST * TILE_B);  // [NW waves][64 lanes][8]: partial S^T and Gram tiles
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -67,6 +73,8 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
     const int P = p.P, nt = P >> 4;
     const T* X = (const T*)p.patches + (long)unit * p.unit_stride;
     const T* posF = (const T*)p.posF + (long)cam * P * D;
+    const int frag_row = li * ROWB;
+    const int fsw = f_swz(li);
 
     // ---- per-lane LDS-DMA source offsets (bytes within a tile), identical for every tile ----
     int src_off[NLD];
@@ -84,14 +92,14 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + src_off[i]), LDS_PTR(dst + (wave * NLD + i) * 1024), 16, 0, 0);
     };
     stage(0, 0);
-    if (nt > 1) stage(1, 1);
+    if (PF > 1 && nt > 1) stage(1, 1);
 
     // ---- text rows: L2-normalise in fp32, store as 16-bit (swizzled) ; rows >= K are zero ----
     {
         const int b = m / p.t_rep;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {                 // unrolled: the loads of the wave's four rows are in flight together
-            const int r = wave * 4 + rr;
+        for (int rr = 0; rr < TRW; ++rr) {               // unrolled: the loads of the wave's rows are in flight together
+            const int r = wave * TRW + rr;
             const float* src = p.text + ((long)b * p.K + r) * D;
             float sq = 0.f;
             f32x4 v[(D / 4 + 63) / 64];
@@ -117,16 +125,19 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
             }
         }
     }
-    const float temp = fminf(fmaxf(p.temperature[cam], 0.f), 100.f);
-    const float inv_temp = 1.0f / temp;
-
-    f32x4 o[NDT];
+    // each wave keeps the text fragments of its D/NW columns in registers for the whole unit
+    __syncthreads();
+    v8 tfr[KSW];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < KSW; ++kk) tfr[kk] = *(const v8*)(sT + frag_row + ((((wave * KSW + kk) * 4 + g) ^ fsw) << 4));
+    const float temp = fminf(fmaxf(p.temperature[cam], 0.f), 100.f);
+    const float inv_temp = 1.4426950408889634f / temp;      // logits are kept in log2 units: softmax through v_exp_f32 (2^x)
+
+    f32x4 o[NDTW];
+#pragma unroll
+    for (int dt = 0; dt < NDTW; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float run_max = -INFINITY, run_sum = 0.f;
 
-    const int frag_row = li * ROWB;
-    const int fsw = f_swz(li);
     // transposed-read addressing: lane li of group g -> row 4g + (li>>2), 8 bytes at column 4*(li&3) of the d-tile
     const int tr_row = 4 * g + (li >> 2);
     const int tr_fsw = f_swz(tr_row);
@@ -148,13 +159,13 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
         // covers two d-tiles (L2-resident table).  Issued first, consumed after the similarity phase; from inline asm
         // because the compiler would wait for them with vmcnt(0), draining the tile prefetch issued right after --
         // the counted wait before their first use is placed by hand below.
-        s16x8 pt[NDT / 2];
+        s16x8 pt[NDTW / 2];
 #pragma unroll
-        for (int dp = 0; dp < NDT / 2; ++dp) {
-            const T* src = posF + ((long)t * 4 + wave) * (NDT * 256) + (dp * 64 + lane) * 8;
+        for (int dp = 0; dp < NDTW / 2; ++dp) {
+            const T* src = posF + (((long)t * NW + wave) * (NDTW / 2) + dp) * 512 + lane * 8;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pt[dp]) : "v"(src) : "memory");
         }
-        if constexpr (PREFETCH) stage((t + 2) % NST, t + 2);
+        if constexpr (PREFETCH) stage((t + PF) % NST, t + PF);
 
         // ---- partial S^T (patch x text) and Gram diagonal over this wave's quarter of D ----
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, gd = {0.f, 0.f, 0.f, 0.f};
@@ -163,17 +174,16 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
             const int ks = wave * KSW + kk;
             const int coff = (((ks * 4 + g) ^ fsw) << 4);
             const v8 xf = *(const v8*)(xb + frag_row + coff);
-            const v8 tf = *(const v8*)(sT + frag_row + coff);
-            s = Half16<T>::mfma32(xf, tf, s);
+            s = Half16<T>::mfma32(xf, tfr[kk], s);
             gd = Half16<T>::mfma32(xf, xf, gd);
         }
-        float* pp = sP + (t & 1) * 2048;
+        float* pp = sP;                                  // reused every tile: the tile's first barrier separates the uses
         *(f32x4*)(pp + (wave * 64 + lane) * 8) = s;
         *(f32x4*)(pp + (wave * 64 + lane) * 8 + 4) = gd;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += *(const f32x4*)(pp + (w * 64 + lane) * 8);
+        for (int w = 0; w < NW; ++w) s += *(const f32x4*)(pp + (w * 64 + lane) * 8);
         // |x|^2 of patch 4g+r sits on lane (g, li = 4g+r), Gram register r, of every wave's partial
         float a1[4], a2[4];
         float tmax = -INFINITY;
@@ -181,8 +191,8 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
         for (int r = 0; r < 4; ++r) {
             float n2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) n2 += pp[(w * 64 + g * 16 + 4 * g + r) * 8 + 4 + r];
-            const float rn = 1.0f / sqrtf(n2);
+            for (int w = 0; w < NW; ++w) n2 += pp[(w * 64 + g * 16 + 4 * g + r) * 8 + 4 + r];
+            const float rn = __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));     // F.normalize: x / max(|x|, 1e-12)
             a1[r] = rn;
             a2[r] = s[r] * rn * inv_temp;                 // logit of (patch 4g+r, text li)
             tmax = fmaxf(tmax, a2[r]);
@@ -190,43 +200,43 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float new_max = fmaxf(run_max, tmax);
-        const float alpha = __expf(run_max - new_max);     // first tile: exp(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f(run_max - new_max);     // first tile: exp(-inf) = 0
         run_max = new_max;
         float psum = 0.f;
         s16x4 b1, b2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float pr = __expf(a2[r] - new_max);
+            const float pr = __builtin_amdgcn_exp2f(a2[r] - new_max);
             psum += pr;
             b1[r] = bits16(Half16<T>::from(pr * a1[r]));
             b2[r] = bits16(Half16<T>::from(pr));
         }
         run_sum = run_sum * alpha + psum;                   // per-lane partial (its own 4 patches per tile)
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+        for (int dt = 0; dt < NDTW; ++dt) o[dt] *= alpha;
 
         // ---- O^T += X^T (p/|x|) + pos^T p ----
         // the pos^T loads are older than the NLD prefetch instructions issued after them (in-order retirement);
         // the "+v" operands tie every later use of pt[] to this wait
 #pragma unroll
-        for (int dp = 0; dp < NDT / 2; ++dp) {
+        for (int dp = 0; dp < NDTW / 2; ++dp) {
             if constexpr (PREFETCH) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pt[dp]) : "n"(NLD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pt[dp]) : : "memory");
         }
         // X^T fragments by ds_read_b64_tr_b16, also from inline asm: after an LDS-DMA the compiler puts vmcnt(0) in
         // front of the builtin form of this read (it cannot tell that the buffers differ), draining the prefetch
-        s16x4 xt[NDT];
+        s16x4 xt[NDTW];
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const int d0 = (wave * NDT + dt) * 16;
+        for (int dt = 0; dt < NDTW; ++dt) {
+            const int d0 = (wave * NDTW + dt) * 16;
             const int chunk = (d0 >> 3) + ((li & 3) >> 1);
             const unsigned addr = (unsigned)(uintptr_t)LDS_PTR(xb + tr_row * ROWB + ((chunk ^ tr_fsw) << 4) + tr_sub);
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xt[dt]) : "v"(addr) : "memory");
         }
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xt[dt]) : : "memory");
+        for (int dt = 0; dt < NDTW; ++dt) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xt[dt]) : : "memory");
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
+        for (int dt = 0; dt < NDTW; ++dt) {
             o[dt] = Half16<T>::mfma16(xt[dt], b1, o[dt]);
             const s16x8 pp2 = pt[dt >> 1];
             const s16x4 ph = (dt & 1) ? (s16x4){pp2[4], pp2[5], pp2[6], pp2[7]} : (s16x4){pp2[0], pp2[1], pp2[2], pp2[3]};
@@ -237,9 +247,14 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
         using Y = std::true_type;
         using N = std::false_type;
         int t = 0;
-        for (; t + 2 < nt; ++t) tile_step(t, Y{}, Y{});
-        if (t + 1 < nt) { tile_step(t, N{}, Y{}); ++t; }
-        if (t < nt) tile_step(t, N{}, N{});
+        if constexpr (NST == 3) {                  // two tiles ahead
+            for (; t + 2 < nt; ++t) tile_step(t, Y{}, Y{});
+            if (t + 1 < nt) { tile_step(t, N{}, Y{}); ++t; }
+            if (t < nt) tile_step(t, N{}, N{});
+        } else {                                   // one tile ahead: nothing younger than tile t is in flight when it is awaited
+            for (; t + 1 < nt; ++t) tile_step(t, Y{}, N{});
+            if (t < nt) tile_step(t, N{}, N{});
+        }
     }
 
     run_sum += __shfl_xor(run_sum, 16, 64);
@@ -248,17 +263,17 @@ __global__ __launch_bounds__(256) void tave_kernel(TaveArgs p) {
     if (li < p.K) {
         float* dst = p.out + (((long)cam * p.M + m) * p.K + li) * D;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const int d0 = (wave * NDT + dt) * 16;
+        for (int dt = 0; dt < NDTW; ++dt) {
+            const int d0 = (wave * NDTW + dt) * 16;
             *(f32x4*)(dst + d0 + 4 * g) = o[dt] * inv;
         }
     }
 }
 
-template <typename T, int NDT>
-int launch_tave(const TaveArgs& a, hipStream_t s) {
-    constexpr int lds = 4 * 16 * NDT * 64 * 2 + 2 * 4 * 64 * 8 * 4;       // text image + 3 patch tiles + partial-tile exchange
-    auto kern = tave_kernel<T, NDT>;
+template <typename T, int D, int NW, int NST, int WGS>
+int launch_tave_n(const TaveArgs& a, hipStream_t s) {
+    constexpr int lds = NST * 16 * D * 2 + NW * 64 * 8 * 4;   // patch tiles (text image borrows one) + partial-tile exchange
+    auto kern = tave_kernel<T, D, NW, NST, WGS>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -268,13 +283,21 @@ int launch_tave(const TaveArgs& a, hipStream_t s) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.units), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.units), dim3(NW * 64), lds, s, a);
     OTTER_CHECK_LAUNCH("otter_text_aware_pool_fwd");
     return OTTER_OK;
 }
 
-// pos_emb [P][D] fp32 -> 16-bit table in the order tave_kernel's lanes consume it:
-//   packed[((t*4 + w)*(NDT/2) + dp)*64 + lane][h*4 + j] = pos[16t + 4g + j][(w*NDT + 2dp + h)*16 + li],  g = lane>>4, li = lane&15
+template <typename T, int D>
+int launch_tave(const TaveArgs& a, hipStream_t s) {
+    // Two buffers of 16 patches: measured against three (same occupancy) and against 8 waves per workgroup, this
+    // is the fastest form at every unit count; the per-tile dependent chain, not the prefetch depth, sets the pace.
+    return launch_tave_n<T, D, 4, 2, 2>(a, s);
+}
+
+// pos_emb [P][D] fp32 -> 16-bit table in the order tave_kernel's lanes consume it (ndt = D/64):
+//   packed[((t*4 + w)*(ndt/2) + dp)*64 + lane][h*4 + j] = pos[16t + 4g + j][(w*ndt + 2dp + h)*16 + li],  g = lane>>4, li = lane&15
+// i.e. 512-element blocks, one per (tile t, pair of d-tiles), pairs in column order -- independent of the wave count.
 // (setup-time kernel, one thread per element)
 template <typename T>
 __global__ void pos_pack_kernel(const float* pos, T* packed, int P, int D) {
@@ -292,10 +315,10 @@ __global__ void pos_pack_kernel(const float* pos, T* packed, int P, int D) {
 template <typename T>
 int dispatch_tave(const TaveArgs& a, int D, hipStream_t s) {
     switch (D) {
-        case 128: return launch_tave<T, 2>(a, s);
-        case 512: return launch_tave<T, 8>(a, s);
-        case 768: return launch_tave<T, 12>(a, s);
-        case 1024: return launch_tave<T, 16>(a, s);
+        case 128: return launch_tave<T, 128>(a, s);
+        case 512: return launch_tave<T, 512>(a, s);
+        case 768: return launch_tave<T, 768>(a, s);
+        case 1024: return launch_tave<T, 1024>(a, s);
     }
     otter_set_error("otter_text_aware_pool_fwd: D=%d unsupported (128, 512, 768, 1024)", D);
     return OTTER_ERR_UNSUPPORTED_SHAPE;

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 4
+#define OTTER_HIP_ABI_VERSION 5
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -99,14 +99,17 @@ int otter_attn_policy(const float* qkv, long ld, float* out, long ldo, int batch
  * patches: un-normalised projected patch tokens; unit u = m*cams + c is the row-major [P][D] block at
  *   patches + u*unit_stride (unit_stride in elements, >= P*D; lets the caller skip the class-token row);
  * text: fp32 [n_obs/t_rep][K][D] un-normalised projected text tokens (observation m uses row m / t_rep);
- * pos_packed: [cams][P*D], every camera's pos_emb packed by otter_pos_emb_pack; out: fp32 [cams][n_obs][K][D].
- * K <= 16, P % 16 == 0, D in {128, 512, 768, 1024}. */
+ * pos_packed: [cams][otter_pos_emb_packed_elems(P, D)], every camera's pos_emb packed by otter_pos_emb_pack;
+ * out: fp32 [cams][n_obs][K][D].  K <= 16, any P >= 1 (ViT-B/16: 196, ViT-L/14: 256, ViT-L/14@336px: 576),
+ * D in {128, 512, 768, 1024}. */
 int otter_text_aware_pool_fwd(int dtype, const void* patches, long unit_stride, const float* text, const void* pos_packed,
                               const float* temperature, float* out, int n_obs, int cams, int P, int D, int K, int t_rep,
                               void* stream);
 /* pos_emb buffer (sincos_position_embedding, models.py:5-12,19-20) [P][D] fp32 -> 16-bit table in the order the
- * pooling kernel's lanes read it (16-byte coalesced loads). */
-int otter_pos_emb_pack(int dtype, const float* pos /* [P][D] fp32 */, void* packed /* [P*D] bf16|fp16 */, int P, int D, void* stream);
+ * pooling kernel's lanes read it (16-byte coalesced loads); P is rounded up to a multiple of 16 with zero rows. */
+long otter_pos_emb_packed_elems(int P, int D);
+int otter_pos_emb_pack(int dtype, const float* pos /* [P][D] fp32 */, void* packed /* [otter_pos_emb_packed_elems] bf16|fp16 */,
+                       int P, int D, void* stream);
 
 /* Query side of AttentionPooling (otter/policy/transformer.py:162-232) after the k/v projections.
  * All weights fp32, matrices transposed to [in][out]. */

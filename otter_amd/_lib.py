@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
@@ -92,6 +92,8 @@ def load() -> ctypes.CDLL:
         fn.restype = c_int
     lib.otter_grad_stats_workspace_floats.restype = c_long
     lib.otter_grad_stats_workspace_floats.argtypes = []
+    lib.otter_pos_emb_packed_elems.restype = c_long
+    lib.otter_pos_emb_packed_elems.argtypes = [c_int, c_int]
     _lib = lib
     return lib
 
@@ -104,4 +106,5 @@ def call(name: str, *args) -> None:
 
 
 def exported_names():
-    return sorted(list(_SIGNATURES) + ["otter_last_error", "otter_hip_abi_version", "otter_grad_stats_workspace_floats"])
+    return sorted(list(_SIGNATURES) + ["otter_last_error", "otter_hip_abi_version", "otter_grad_stats_workspace_floats",
+                                            "otter_pos_emb_packed_elems"])

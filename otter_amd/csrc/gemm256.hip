@@ -337,6 +337,7 @@ bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K,
     if (M < 1024 || N < 256 || K % 64 != 0) return false;                       // small problems: 128x128 tiles fill the chip better
     if (N % 8 != 0 || ldc % 8 != 0 || ((uintptr_t)C & 15) != 0) return false;     // a lane stores 8 consecutive columns as 16-byte vectors
     if (n_pad < ((N + TN - 1) / TN) * TN) return false;                          // weight rows must cover whole 256-column tiles
+    if ((long)(M / TM) * ((N + TN - 1) / TN) < 128) return false;                // fewer tiles than half the CUs: smaller tiles fill the chip better
     if ((long)M * lda * 2 >= (1L << 32) || (long)n_pad * K * 2 >= (1L << 32)) return false;   // 32-bit source offsets
     return true;
 }

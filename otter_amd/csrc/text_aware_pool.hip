@@ -45,6 +45,21 @@ __device__ __forceinline__ int f_swz(int r) {
     return (((lo + 4 * hi) & 7) << 1) | hi;
 }
 
+// reductions over the four 16-lane rows of a wave (same lane index li in every row) with v_permlane{32,16}_swap: VALU only,
+// no LDS round trip.  Every lane ends up with the result.
+__device__ __forceinline__ float rows_max(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // NW waves per workgroup: each reduces D/NW columns of the similarity product and owns D/NW output columns (NDTW d-tiles
 // of 16).  NST = patch-tile buffers in LDS (prefetch distance NST-1 tiles).  WGS = workgroups the register budget lets
 // share a CU: the waves of co-resident workgroups overlap each other's dependent chains.
@@ -64,15 +79,15 @@ __global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
     static_assert(NDTW >= 2 && NDTW % 2 == 0 && KSW >= 1 && NLD >= 1 && NST >= 2, "unsupported D / wave count");
     char* sX = smem;
     char* sT = smem + (NST - 1) * TILE_B;       // text image: borrows the buffer that the first prefetch fills last
-    float* sP = (float*)(smem + NST * TILE_B);  // [NW waves][64 lanes][8]: partial S^T and Gram tiles
+    float* sP = (float*)(smem + NST * TILE_B);  // [NW waves][64 lanes][4] partial S^T tiles, then [NW waves][16] partial |x|^2
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int unit = blockIdx.x;
     const int m = unit / p.cams, cam = unit % p.cams;
-    const int P = p.P, nt = P >> 4;
+    const int P = p.P, nt = (P + 15) >> 4;     // the last tile may be partial: its missing rows are masked out of the softmax
     const T* X = (const T*)p.patches + (long)unit * p.unit_stride;
-    const T* posF = (const T*)p.posF + (long)cam * P * D;
+    const T* posF = (const T*)p.posF + (long)cam * (nt * 16) * D;
     const int frag_row = li * ROWB;
     const int fsw = f_swz(li);
 
@@ -86,10 +101,11 @@ __global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
     }
     auto stage = [&](int buf, int tile) {
         const char* base = (const char*)(X + (long)tile * 16 * D);
+        const int lim = (P - tile * 16) * ROWB - 16;         // chunks past the unit's last row re-read its last chunk (finite, masked)
         char* dst = sX + buf * TILE_B;
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + src_off[i]), LDS_PTR(dst + (wave * NLD + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + min(src_off[i], lim)), LDS_PTR(dst + (wave * NLD + i) * 1024), 16, 0, 0);
     };
     stage(0, 0);
     if (PF > 1 && nt > 1) stage(1, 1);
@@ -178,27 +194,28 @@ __global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
             gd = Half16<T>::mfma32(xf, xf, gd);
         }
         float* pp = sP;                                  // reused every tile: the tile's first barrier separates the uses
-        *(f32x4*)(pp + (wave * 64 + lane) * 8) = s;
-        *(f32x4*)(pp + (wave * 64 + lane) * 8 + 4) = gd;
+        float* pg = sP + NW * 256;                       // [NW waves][16 patches]: the partial Gram diagonals
+        *(f32x4*)(pp + (wave * 64 + lane) * 4) = s;
+        // |x|^2 of patch 4g+r sits on lane (g, li = 4g+r), Gram register r
+        if ((li >> 2) == g) pg[wave * 16 + li] = (li & 2) ? ((li & 1) ? gd[3] : gd[2]) : ((li & 1) ? gd[1] : gd[0]);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 n2 = s;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) s += *(const f32x4*)(pp + (w * 64 + lane) * 8);
-        // |x|^2 of patch 4g+r sits on lane (g, li = 4g+r), Gram register r, of every wave's partial
+        for (int w = 0; w < NW; ++w) {
+            s += *(const f32x4*)(pp + (w * 64 + lane) * 4);
+            n2 += *(const f32x4*)(pg + w * 16 + 4 * g);
+        }
         float a1[4], a2[4];
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float n2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) n2 += pp[(w * 64 + g * 16 + 4 * g + r) * 8 + 4 + r];
-            const float rn = __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));     // F.normalize: x / max(|x|, 1e-12)
+            const float rn = __builtin_amdgcn_rsqf(fmaxf(n2[r], 1e-24f));  // F.normalize: x / max(|x|, 1e-12)
             a1[r] = rn;
-            a2[r] = s[r] * rn * inv_temp;                 // logit of (patch 4g+r, text li)
+            a2[r] = (t * 16 + 4 * g + r < P) ? s[r] * rn * inv_temp : -INFINITY;   // logit of (patch 4g+r, text li)
             tmax = fmaxf(tmax, a2[r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = rows_max(tmax);
         const float new_max = fmaxf(run_max, tmax);
         const float alpha = __builtin_amdgcn_exp2f(run_max - new_max);     // first tile: exp(-inf) = 0
         run_max = new_max;
@@ -257,8 +274,7 @@ __global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
         }
     }
 
-    run_sum += __shfl_xor(run_sum, 16, 64);
-    run_sum += __shfl_xor(run_sum, 32, 64);
+    run_sum = rows_sum(run_sum);
     const float inv = 1.0f / run_sum;
     if (li < p.K) {
         float* dst = p.out + (((long)cam * p.M + m) * p.K + li) * D;
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
 
 template <typename T, int D, int NW, int NST, int WGS>
 int launch_tave_n(const TaveArgs& a, hipStream_t s) {
-    constexpr int lds = NST * 16 * D * 2 + NW * 64 * 8 * 4;   // patch tiles (text image borrows one) + partial-tile exchange
+    constexpr int lds = NST * 16 * D * 2 + NW * (64 * 4 + 16) * 4;   // patch tiles (text image borrows one) + partial-tile exchange
     auto kern = tave_kernel<T, D, NW, NST, WGS>;
     static bool configured = false;
     if (!configured) {
@@ -297,19 +313,21 @@ int launch_tave(const TaveArgs& a, hipStream_t s) {
 
 // pos_emb [P][D] fp32 -> 16-bit table in the order tave_kernel's lanes consume it (ndt = D/64):
 //   packed[((t*4 + w)*(ndt/2) + dp)*64 + lane][h*4 + j] = pos[16t + 4g + j][(w*ndt + 2dp + h)*16 + li],  g = lane>>4, li = lane&15
+// (rows past P are zero: P is rounded up to whole 16-patch tiles)
 // i.e. 512-element blocks, one per (tile t, pair of d-tiles), pairs in column order -- independent of the wave count.
 // (setup-time kernel, one thread per element)
 template <typename T>
-__global__ void pos_pack_kernel(const float* pos, T* packed, int P, int D) {
+__global__ void pos_pack_kernel(const float* pos, T* packed, int P, int D, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)P * D) return;
+    if (i >= n) return;
     const int ndt = D / 64;
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
     long rest = i >> 9;
     const int dp = (int)(rest % (ndt / 2)); rest /= (ndt / 2);
     const int w = (int)(rest & 3), t = (int)(rest >> 2);
     const int h = e >> 2, j = e & 3, g = lane >> 4, li = lane & 15;
-    packed[i] = Half16<T>::from(pos[(long)(16 * t + 4 * g + j) * D + (w * ndt + 2 * dp + h) * 16 + li]);
+    const int row = 16 * t + 4 * g + j;
+    packed[i] = Half16<T>::from(row < P ? pos[(long)row * D + (w * ndt + 2 * dp + h) * 16 + li] : 0.f);
 }
 
 template <typename T>
@@ -335,7 +353,7 @@ extern "C" int otter_text_aware_pool_fwd(int dtype, const void* patches, long un
     OTTER_REQUIRE(n_obs > 0 && cams > 0 && t_rep > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: bad sizes");
     OTTER_REQUIRE(n_obs % t_rep == 0, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: n_obs=%d not a multiple of t_rep=%d", n_obs, t_rep);
     OTTER_REQUIRE(K >= 1 && K <= 16, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_fwd: K=%d text tokens, supports 1..16", K);
-    OTTER_REQUIRE(P >= 16 && P % 16 == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_fwd: P=%d must be a multiple of 16", P);
+    OTTER_REQUIRE(P >= 1 && (long)P * D < (1L << 30), OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: P=%d patches", P);
     OTTER_REQUIRE(aligned16(patches) && aligned16(text) && aligned16(pos_packed) && aligned16(out), OTTER_ERR_ALIGNMENT,
                   "otter_text_aware_pool_fwd: operands must be 16-byte aligned");
     OTTER_REQUIRE((long)n_obs * cams < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_fwd: grid too large");
@@ -346,15 +364,17 @@ extern "C" int otter_text_aware_pool_fwd(int dtype, const void* patches, long un
     return dtype == DT_BF16 ? dispatch_tave<__bf16>(a, D, s) : dispatch_tave<_Float16>(a, D, s);
 }
 
+extern "C" long otter_pos_emb_packed_elems(int P, int D) { return (long)((P + 15) / 16) * 16 * D; }
+
 extern "C" int otter_pos_emb_pack(int dtype, const float* pos, void* packed, int P, int D, void* stream) {
     OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_pos_emb_pack: dtype %d (bf16 or fp16)", dtype);
-    OTTER_REQUIRE(pos && packed && P > 0 && D > 0 && P % 16 == 0 && D % 128 == 0, OTTER_ERR_INVALID_ARGUMENT,
-                  "otter_pos_emb_pack: bad arguments (P %% 16 == 0, D %% 128 == 0)");
-    const long n = (long)P * D;
+    OTTER_REQUIRE(pos && packed && P > 0 && D > 0 && D % 128 == 0, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_pos_emb_pack: bad arguments (P > 0, D %% 128 == 0)");
+    const long n = otter_pos_emb_packed_elems(P, D);
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL(pos_pack_kernel<__bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (__bf16*)packed, P, D);
+        hipLaunchKernelGGL(pos_pack_kernel<__bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (__bf16*)packed, P, D, n);
     else
-        hipLaunchKernelGGL(pos_pack_kernel<_Float16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (_Float16*)packed, P, D);
+        hipLaunchKernelGGL(pos_pack_kernel<_Float16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, (_Float16*)packed, P, D, n);
     OTTER_CHECK_LAUNCH("otter_pos_emb_pack");
     return OTTER_OK;
 }

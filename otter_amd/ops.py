@@ -225,12 +225,12 @@ def attn_policy(qkv_cache: Tensor, n_query: int, pos0: int, heads: int) -> Tenso
 
 
 def pos_emb_pack(pos: Tensor, dtype=torch.bfloat16) -> Tensor:
-    """pos_emb (P, D) fp32 -> (P*D,) 16-bit table in the order the pooling kernel's lanes read it."""
+    """pos_emb (P, D) fp32 -> (ceil(P/16)*16*D,) 16-bit table in the order the pooling kernel's lanes read it."""
     _chk(pos, torch.float32, "pos_emb", 2)
     if not pos.is_contiguous():
         raise ValueError("pos_emb must be contiguous")
     p, d = pos.shape
-    out = torch.empty(p * d, dtype=dtype, device=pos.device)
+    out = torch.empty(-(-p // 16) * 16 * d, dtype=dtype, device=pos.device)
     _lib.call("otter_pos_emb_pack", _dt(dtype, "pos_emb_pack", False), _ptr(pos), _ptr(out), p, d, _stream())
     return out
 
@@ -241,7 +241,7 @@ def text_aware_pool(patches: Tensor, text: Tensor, pos_packed: Tensor, temperatu
 
     patches bf16/fp16: either (n_obs*cams, P, D) contiguous, or (n_obs*cams, L, D) with ``n_patches`` = P < L given,
     in which case the LAST P rows of each unit are used (skips the class token of a ViT output);
-    text fp32 (n_obs/t_rep, K, D); pos_packed (cams, P*D) from :func:`pos_emb_pack` in the patches' dtype;
+    text fp32 (n_obs/t_rep, K, D); pos_packed (cams, ceil(P/16)*16*D) from :func:`pos_emb_pack` in the patches' dtype;
     -> fp32 (cams, n_obs, K, D).
     """
     dt = _dt(patches.dtype, "tave.patches", False)
@@ -254,7 +254,7 @@ def text_aware_pool(patches: Tensor, text: Tensor, pos_packed: Tensor, temperatu
     nt, k, d2 = text.shape
     if units != n_obs * cams or d2 != d or n_obs % t_rep != 0 or nt != n_obs // t_rep or p > rows:
         raise ValueError(f"tave: patches {tuple(patches.shape)}, text {tuple(text.shape)}, n_obs={n_obs}, cams={cams}, t_rep={t_rep}")
-    if tuple(pos_packed.shape) != (cams, p * d) or temperature.numel() != cams:
+    if tuple(pos_packed.shape) != (cams, -(-p // 16) * 16 * d) or temperature.numel() != cams:
         raise ValueError("tave: pos_packed / temperature shape mismatch")
     for t in (patches, text, pos_packed, temperature):
         if not t.is_contiguous():

@@ -235,7 +235,9 @@ def test_attn_policy(dev, b, s, nq, pos0, heads, hd):
 
 
 @pytest.mark.parametrize("n_obs,cams,P,D,K,t_rep", [(2, 2, 256, 768, 15, 1), (6, 2, 256, 768, 15, 3), (3, 1, 64, 128, 15, 1),
-                                                    (2, 2, 16, 128, 1, 2), (1, 2, 256, 768, 16, 1)])
+                                                    (2, 2, 16, 128, 1, 2), (1, 2, 256, 768, 16, 1),
+                                                    # patch counts that are not whole 16-row tiles: ViT-B/16 (196), ViT-B/32 (49), ...
+                                                    (2, 2, 196, 512, 15, 1), (3, 1, 49, 512, 15, 1), (2, 1, 5, 128, 3, 1), (1, 2, 577, 768, 15, 1)])
 @pytest.mark.parametrize("temperature", [0.07, 0.005, 150.0])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_text_aware_pool(dev, n_obs, cams, P, D, K, t_rep, temperature, dtype):

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 5
+#define OTTER_HIP_ABI_VERSION 6
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -33,7 +33,7 @@ extern "C" {
 #define OTTER_EPI_ACT_RELU 3      /* action head / proprio MLP (models.py:42-47,58-62) */
 #define OTTER_EPI_ACT_MASK 3
 #define OTTER_EPI_OUT_F32 4       /* write fp32 instead of the 16-bit operand type (always on for fp32 operands) */
-#define OTTER_EPI_RESIDUAL 8      /* out = acc + bias + residual (fp32), requires OUT_F32 and ACT_NONE */
+#define OTTER_EPI_RESIDUAL 8      /* out = acc + bias + residual; residual has the OUTPUT's type (fp32 with OUT_F32, else the operand type); ACT_NONE */
 #define OTTER_EPI_TILE_128 16     /* tuning knob: always use the 128x128-tile kernel (default picks 256x256 for big shapes) */
 
 int otter_hip_abi_version(void);
@@ -49,26 +49,27 @@ const char* otter_last_error(void);
  * called at otter/policy/otter.py:189-190), `@ visual.proj` / `@ text_projection` (otter.py:194,212),
  * policy query/key/value/out/mlp (otter/policy/transformer.py:64-69,114-118), input_projection (otter.py:262),
  * action head (otter/policy/models.py:58-62), pooling k/v projections (transformer.py:165-171). */
-int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const float* residual,
+int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const void* residual,
                long ldr, void* C, long ldc, int M, int N, int K, int epilogue, void* stream);
 
-/* y[r,:] = LayerNorm(x[r,:]) * gamma + beta  (fp32 in; out_dtype = OTTER_DT_*; gamma/beta NULL = no affine).
+/* y[r,:] = LayerNorm(x[r,:]) * gamma + beta  (in_dtype / out_dtype = OTTER_DT_*: x may be the fp32 or the 16-bit
+ * residual stream; statistics in fp32; gamma/beta NULL = no affine).
  * Replaces ln_1/ln_2/ln_post/ln_final of CLIP (otter.py:194,209), pre_ln/post_ln (transformer.py:111-112,133,138),
  * kv_layer_norm (transformer.py:190). */
-int otter_layernorm(const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, int rows,
+int otter_layernorm(const void* x, int in_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy, int rows,
                     int width, float eps, int out_dtype, void* stream);
 
 /* ViT input: x[i, t, :] = ln_pre((t == 0 ? class_embedding : patch_tok[i, t-1, :]) + positional_embedding[t, :]).
  * Replaces the class-token concat + positional add + ln_pre inside clip's VisionTransformer.forward
  * (reached from otter.py:190). */
 int otter_vit_embed_lnpre(const float* patch_tok, long ld_tok, const float* class_embedding, const float* pos_embedding,
-                          const float* gamma, const float* beta, float* x, long ldx, int n_img, int n_patches, int width,
-                          float eps, void* stream);
+                          const float* gamma, const float* beta, void* x /* out_dtype */, int out_dtype, long ldx, int n_img,
+                          int n_patches, int width, float eps, void* stream);
 
 /* Text-tower input: x[b*take + t, :] = token_embedding[ids[b*ctx + t]] + positional_embedding[t], t < take.
  * (clip.encode_text reached from otter.py:189; only the first `take` positions are needed, otter.py:193.) */
 int otter_text_embed(const int* ids, int ctx, int take, const float* token_embedding, int vocab, const float* pos_embedding,
-                     float* x, long ldx, int batch, int width, void* stream);
+                     void* x /* out_dtype */, int out_dtype, long ldx, int batch, int width, void* stream);
 
 /* Patch extraction for the stride=kernel conv1 of the ViT as a GEMM operand:
  * out[(i*g*g + py*g + px), c*p*p + ky*p + kx] = pixel(i, c, py*p+ky, px*p+kx), zero-padded to kpad columns

@@ -56,7 +56,10 @@ __global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
             qf[ks] = *(const v8*)(qkv + (row0 + qc) * p.ld + h * 64 + ks * 32 + g * 8);
     };
     v8 qf[2];
-    load_q(wave < NT ? wave : 0, qf);
+    // NT is rarely a multiple of NW, so some wave gets one tile more; which one rotates with the workgroup id so that the
+    // workgroups sharing a CU do not all put their extra tile on the same SIMD
+    const int wslot = (wave + (blockIdx.x ^ (blockIdx.x >> 3) ^ (blockIdx.x >> 8))) % NW;
+    load_q(wslot < NT ? wslot : 0, qf);
 
     // ---- stage K and V of this head by LDS-DMA: one instruction = 8 rows x 128 bytes, lane-linear destination, the
     //      chunk swizzle applied on the source address.  Rows >= L repeat row L-1 (finite data; their keys are masked). ----
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
     const int vr = li >> 2;
     const float c2 = p.scale * 1.44269504088896341f;     // softmax(scale*s) = 2^(c2*s - c2*max) / sum
 
-    for (int qt = wave; qt < NT; qt += NW) {
+    for (int qt = wslot; qt < NT; qt += NW) {
         const int q = qt * 16 + li;                // this lane's query
         // Every key tile is computed, also rows past L: a wave-uniform skip here would put a branch between an
         // MFMA and the first read of its accumulator.
@@ -85,14 +88,39 @@ __global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
         // flight.  An opaque copy of the row offset keeps the (cheap) LDS reads inside the loop.
         int k_row = k_row_off;
         asm volatile("" : "+v"(k_row));
+        // A wave issues in order and has at most one partner wave on its SIMD, so LDS latency is hidden by hand: the K
+        // fragments of the next batch of key tiles are requested before the MFMAs of the current batch are issued.
         f32x4 s[NT];
+        {
+            constexpr int KB = 4, NB = (NT + KB - 1) / KB;
+            v8 kf[2][KB][2];
+            auto read_k = [&](int b, v8 (&dst)[KB][2]) {
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < KB; ++i)
+                    if (b * KB + i < NT) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const v8 kf = *(const v8*)(sK + kt * 2048 + k_row + (((ks * 4 + g) ^ k_sw) << 4));
-                s[kt] = Half16<T>::mfma32(kf, qf[ks], s[kt]);
+                        for (int ks = 0; ks < 2; ++ks)
+                            dst[i][ks] = *(const v8*)(sK + (b * KB + i) * 2048 + k_row + (((ks * 4 + g) ^ k_sw) << 4));
+                    }
+            };
+            read_k(0, kf[0]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b + 1 < NB) read_k(b + 1, kf[(b + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < KB; ++i)
+                    if (b * KB + i < NT) {
+                        const int kt = b * KB + i;
+                        s[kt] = Half16<T>::mfma32(kf[b & 1][i][0], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f});
+                    }
+#pragma unroll
+                for (int i = 0; i < KB; ++i)
+                    if (b * KB + i < NT) {
+                        const int kt = b * KB + i;
+                        s[kt] = Half16<T>::mfma32(kf[b & 1][i][1], qf[1], s[kt]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (qt + NW < NT) load_q(qt + NW, qf);      // lands while the softmax runs
@@ -108,49 +136,62 @@ __global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
                 if (!known_valid) s[kt][r] = (kt * 16 + r < lim) ? s[kt][r] : -INFINITY;
                 mx = fmaxf(mx, s[kt][r]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float off = -mx * c2;
-        float sum = 0.f;
+        mx = rows_max(mx);
+        // two scores per instruction where the ISA has packed fp32 forms (v_pk_fma_f32, v_pk_add_f32); the exponential is scalar
+        const f32x2 c2v = {c2, c2}, offv = {-mx * c2, -mx * c2};
+        f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, off));     // 2^(-inf) = 0 for masked keys
-                s[kt][r] = e;
-                sum += e;
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 x = __builtin_elementwise_fma((f32x2){s[kt][r], s[kt][r + 1]}, c2v, offv);
+                const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};   // 2^(-inf) = 0 for masked keys
+                s[kt][r] = e[0];
+                s[kt][r + 1] = e[1];
+                sum2 += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        float sum = rows_sum(sum2[0] + sum2[1]);
         const float inv = 1.0f / sum;
 
         // ---- O^T = V^T . P^T ----
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            // V^T fragments (two transposed reads per MFMA) are requested a key-tile pair ahead of their MFMAs
+            v8 vf[2][4];
+            auto read_v = [&](int s2, v8 (&dst)[4]) {
+                const bool has_hi = 2 * s2 + 1 < NT;
 #pragma unroll
-        for (int s2 = 0; s2 < NP; ++s2) {
-            constexpr T zero = (T)0.0f;
-            const bool has_hi = 2 * s2 + 1 < NT;
-            v8 pf;
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int rlo = 32 * s2 + 4 * g + vr, rhi = rlo + 16;
+                    const int cl = dt * 2 + ((li & 3) >> 1), sub = (li & 1) * 8;
+                    union { struct { s16x4 a, b; } h; v8 v; } u;
+                    u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sV + rlo * 128 + (v_swz(rlo, cl) << 4) + sub));
+                    u.h.b = (s16x4){0, 0, 0, 0};
+                    if (has_hi)
+                        u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(sV + rhi * 128 + (v_swz(rhi, cl) << 4) + sub));
+                    dst[dt] = u.v;
+                }
+            };
+            read_v(0, vf[0]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pf[r] = Half16<T>::from_unit(s[2 * s2][r]);
-                pf[4 + r] = has_hi ? Half16<T>::from_unit(s[has_hi ? 2 * s2 + 1 : 0][r]) : zero;
-            }
+            for (int s2 = 0; s2 < NP; ++s2) {
+                constexpr T zero = (T)0.0f;
+                const bool has_hi = 2 * s2 + 1 < NT;
+                if (s2 + 1 < NP) read_v(s2 + 1, vf[(s2 + 1) & 1]);
+                v8 pf;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int rlo = 32 * s2 + 4 * g + vr, rhi = rlo + 16;
-                const int cl = dt * 2 + ((li & 3) >> 1), sub = (li & 1) * 8;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(sV + rlo * 128 + (v_swz(rlo, cl) << 4) + sub));
-                s16x4 hi = {0, 0, 0, 0};
-                if (has_hi)
-                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(sV + rhi * 128 + (v_swz(rhi, cl) << 4) + sub));
-                union { struct { s16x4 a, b; } h; v8 v; } u;
-                u.h.a = lo; u.h.b = hi;
-                o[dt] = Half16<T>::mfma32(u.v, pf, o[dt]);
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = Half16<T>::from_unit(s[2 * s2][r]);
+                    pf[4 + r] = has_hi ? Half16<T>::from_unit(s[has_hi ? 2 * s2 + 1 : 0][r]) : zero;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = Half16<T>::mfma32(vf[s2 & 1][dt], pf, o[dt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (q < L) {

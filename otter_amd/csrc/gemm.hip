@@ -22,12 +22,12 @@
 
 // 256x256-tile kernel for the big 16-bit shapes (gemm256.hip)
 bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc);
-int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                          void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
 
 // 64x64-tile kernel for remainder rows and small problems (gemm_tail.hip)
 bool otter_gemm64_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc);
-int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
 
 namespace {
@@ -41,7 +41,7 @@ struct GemmArgs {
     const char* A; long lda;    // lda, ldw in elements
     const char* W;              // [n_pad][K]
     const float* bias;          // [N] or null
-    const float* residual; long ldr;
+    const void* residual; long ldr;     // in the OUTPUT's type
     void* C; long ldc;
     int M, N, K, tiles_m, tiles_n;
 };
@@ -162,7 +162,15 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128(GemmArgs p) {
             f32x4 v = acc[i][j] + b;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e]);
-            if (RES) v += *(const f32x4*)(p.residual + (long)m * p.ldr + n);
+            if (RES) {
+                if constexpr (OUT_F32 || sizeof(T) == 4) {
+                    v += *(const f32x4*)((const float*)p.residual + (long)m * p.ldr + n);
+                } else {
+                    const typename Half16<T>::v4 r = *(const typename Half16<T>::v4*)((const T*)p.residual + (long)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                }
+            }
             if constexpr (OUT_F32 || sizeof(T) == 4) {
                 *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
             } else {
@@ -199,7 +207,11 @@ int pick_out(const GemmArgs& a, bool out_f32, hipStream_t s) {
 
 template <typename T>
 int dispatch(const GemmArgs& a, int act, bool out_f32, bool res, hipStream_t s) {
-    if (res) return launch<T, ACT_NONE, true, true>(a, s);
+    if constexpr (sizeof(T) == 4) {
+        if (res) return launch<T, ACT_NONE, true, true>(a, s);
+    } else {
+        if (res) return out_f32 ? launch<T, ACT_NONE, true, true>(a, s) : launch<T, ACT_NONE, false, true>(a, s);
+    }
     switch (act) {
         case OTTER_EPI_ACT_NONE: return pick_out<T, ACT_NONE>(a, out_f32, s);
         case OTTER_EPI_ACT_QUICKGELU: return pick_out<T, ACT_QUICKGELU>(a, out_f32, s);
@@ -213,7 +225,7 @@ int dispatch(const GemmArgs& a, int act, bool out_f32, bool res, hipStream_t s) 
 }  // namespace
 
 extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias,
-                          const float* residual, long ldr, void* C, long ldc, int M, int N, int K,
+                          const void* residual, long ldr, void* C, long ldc, int M, int N, int K,
                           int epilogue, void* stream) {
     OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16 || dtype == DT_F32, OTTER_ERR_INVALID_ARGUMENT, "otter_gemm: unknown dtype %d", dtype);
     const int es = dtype == DT_F32 ? 4 : 2;
@@ -233,10 +245,9 @@ extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int
                   "otter_gemm: operands must be 16-byte aligned");
     OTTER_REQUIRE((long)tiles_m * tiles_n < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm: too many tiles");
     if (res) {
-        OTTER_REQUIRE(residual && aligned16(residual) && ldr >= N && ldr % 4 == 0, OTTER_ERR_INVALID_ARGUMENT,
-                      "otter_gemm: residual epilogue needs an aligned fp32 residual with ldr >= N");
-        OTTER_REQUIRE(out_f32 && act == OTTER_EPI_ACT_NONE, OTTER_ERR_UNSUPPORTED_SHAPE,
-                      "otter_gemm: residual epilogue is fp32-out, no activation");
+        OTTER_REQUIRE(residual && aligned16(residual) && ldr >= N && ldr % (out_f32 ? 4 : 8) == 0, OTTER_ERR_INVALID_ARGUMENT,
+                      "otter_gemm: residual epilogue needs a 16-byte aligned residual of the output's type with ldr >= N");
+        OTTER_REQUIRE(act == OTTER_EPI_ACT_NONE, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm: residual epilogue takes no activation");
     }
     hipStream_t s = (hipStream_t)stream;
     if (!(epilogue & OTTER_EPI_TILE_128) && otter_gemm256_eligible(dtype, lda, n_pad, M, N, K, C, ldc)) {
@@ -247,7 +258,7 @@ extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int
         if (rc != OTTER_OK || m_main == M) return rc;
         const long ec = (out_f32 ? 4 : es);
         return otter_gemm64_launch(dtype, (const char*)A + (long)m_main * lda * es, lda, W, bias,
-                                      res ? residual + (long)m_main * ldr : nullptr, ldr, (char*)C + (long)m_main * ldc * ec, ldc,
+                                      res ? (const char*)residual + (long)m_main * ldr * ec : nullptr, ldr, (char*)C + (long)m_main * ldc * ec, ldc,
                                       M - m_main, N, K, act, out_f32, res, s);
     }
     // too few 128x128 tiles to give every CU one: the 64x64 kernel spreads the problem over 4x more workgroups

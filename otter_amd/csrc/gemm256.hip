@@ -41,7 +41,7 @@ struct Gemm256Args {
     const char* A; long lda;
     const char* W;
     const float* bias;
-    const float* residual; long ldr;
+    const void* residual; long ldr;     // in the OUTPUT's type: fp32 with OUT_F32, else the 16-bit operand type
     void* C; long ldc;
     int M, N, K, tiles_m, tiles_n;
 };
@@ -260,9 +260,18 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                         v1[e] = act256<ACT>(v1[e]);
                     }
                     if (RES) {
-                        const float* r = p.residual + (long)m * p.ldr + n;
-                        v0 += *(const f32x4*)r;
-                        v1 += *(const f32x4*)(r + 4);
+                        if constexpr (OUT_F32) {
+                            const float* r = (const float*)p.residual + (long)m * p.ldr + n;
+                            v0 += *(const f32x4*)r;
+                            v1 += *(const f32x4*)(r + 4);
+                        } else {
+                            const typename Half16<T>::v8 r = *(const typename Half16<T>::v8*)((const T*)p.residual + (long)m * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v0[e] += (float)r[e];
+                                v1[e] += (float)r[4 + e];
+                            }
+                        }
                     }
                     if constexpr (OUT_F32) {
                         float* c = (float*)p.C + (long)m * p.ldc + n;
@@ -318,7 +327,7 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
 
 template <typename T>
 int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, hipStream_t s) {
-    if (res) return launch256<T, ACT_NONE, true, true>(a, s);
+    if (res) return out_f32 ? launch256<T, ACT_NONE, true, true>(a, s) : launch256<T, ACT_NONE, false, true>(a, s);
     switch (act) {
         case OTTER_EPI_ACT_NONE: return out_f32 ? launch256<T, ACT_NONE, true, false>(a, s) : launch256<T, ACT_NONE, false, false>(a, s);
         case OTTER_EPI_ACT_QUICKGELU: return out_f32 ? launch256<T, ACT_QUICKGELU, true, false>(a, s) : launch256<T, ACT_QUICKGELU, false, false>(a, s);
@@ -342,7 +351,7 @@ bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K,
     return true;
 }
 
-int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                          void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s) {
     if (M <= 0 || M % TM != 0) {                     // whole 256-row tiles only: the caller sends the remainder elsewhere
         otter_set_error("otter_gemm (256x256): M=%d is not a positive multiple of %d", M, TM);

@@ -16,13 +16,13 @@ namespace {
 constexpr int TB = 64;                                   // tile edge
 constexpr int ROWB = 128;                                // bytes of K per row and K-step
 constexpr int STAGE = 2 * TB * ROWB;                     // 16 KiB
-constexpr int NS = 4;                                    // LDS stages: three K-steps in flight hide the load latency
+// LDS stages NS (template parameter): NS-1 K-steps of loads in flight per workgroup.
 
 struct TailArgs {
     const char* A; long lda;
     const char* W;
     const float* bias;
-    const float* residual; long ldr;
+    const void* residual; long ldr;     // in the OUTPUT's type
     void* C; long ldc;
     int M, N, K, tiles_m, tiles_n;
 };
@@ -50,7 +50,7 @@ __device__ __forceinline__ f32x4 mma_t(const typename TFrag<T>::type& w, const t
     }
 }
 
-template <typename T, int ACT, bool OUT_F32, bool RES>
+template <typename T, int ACT, bool OUT_F32, bool RES, int NS>
 __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TFrag<T>::type frag_t;
@@ -141,9 +141,18 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
             v1[e] = act_t<ACT>(v1[e]);
         }
         if (RES) {
-            const float* r = p.residual + (long)m * p.ldr + n;
-            v0 += *(const f32x4*)r;
-            v1 += *(const f32x4*)(r + 4);
+            if constexpr (OUT_F32 || sizeof(T) == 4) {
+                const float* r = (const float*)p.residual + (long)m * p.ldr + n;
+                v0 += *(const f32x4*)r;
+                v1 += *(const f32x4*)(r + 4);
+            } else {
+                const typename Half16<T>::v8 r = *(const typename Half16<T>::v8*)((const T*)p.residual + (long)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] += (float)r[e];
+                    v1[e] += (float)r[4 + e];
+                }
+            }
         }
         if constexpr (OUT_F32 || sizeof(T) == 4) {
             float* c = (float*)p.C + (long)m * p.ldc + n;
@@ -161,17 +170,28 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
     }
 }
 
-template <typename T, int ACT, bool OUT_F32, bool RES>
-int launch_tail(const TailArgs& a, hipStream_t s) {
-    auto kern = gemm_64x64<T, ACT, OUT_F32, RES>;
+template <typename T, int ACT, bool OUT_F32, bool RES, int NS>
+int launch_tail_ns(const TailArgs& a, hipStream_t s) {
+    auto kern = gemm_64x64<T, ACT, OUT_F32, RES, NS>;
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE);
+        if (e != hipSuccess) {
+            otter_set_error("otter_gemm (64x64): cannot reserve %d bytes of LDS: %s", NS * STAGE, hipGetErrorString(e));
+            return OTTER_ERR_LAUNCH;
+        }
         configured = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), NS * STAGE, s, a);
     OTTER_CHECK_LAUNCH("otter_gemm (64x64)");
     return OTTER_OK;
+}
+
+template <typename T, int ACT, bool OUT_F32, bool RES>
+int launch_tail(const TailArgs& a, hipStream_t s) {
+    // (8 stages for launches with fewer tiles than CUs were measured: no change -- such launches are bound by the 16 KiB
+    //  per K-step that one CU can pull through its L1, not by the pipeline depth)
+    return launch_tail_ns<T, ACT, OUT_F32, RES, 4>(a, s);
 }
 
 template <int ACT>
@@ -191,7 +211,7 @@ int dispatch_tail_f32(const TailArgs& a, int act, bool res, hipStream_t s) {
 
 template <typename T>
 int dispatch_tail(const TailArgs& a, int act, bool out_f32, bool res, hipStream_t s) {
-    if (res) return launch_tail<T, ACT_NONE, true, true>(a, s);
+    if (res) return out_f32 ? launch_tail<T, ACT_NONE, true, true>(a, s) : launch_tail<T, ACT_NONE, false, true>(a, s);
     switch (act) {
         case OTTER_EPI_ACT_NONE: return out_f32 ? launch_tail<T, ACT_NONE, true, false>(a, s) : launch_tail<T, ACT_NONE, false, false>(a, s);
         case OTTER_EPI_ACT_QUICKGELU: return out_f32 ? launch_tail<T, ACT_QUICKGELU, true, false>(a, s) : launch_tail<T, ACT_QUICKGELU, false, false>(a, s);
@@ -213,7 +233,7 @@ bool otter_gemm64_eligible(int dtype, long lda, int n_pad, int M, int N, int K, 
     return (long)M * lda * es < (1L << 32) && (long)n_pad * K * es < (1L << 32);
 }
 
-int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const float* residual, long ldr,
+int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s) {
     TailArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB};
     if (dtype == DT_F32) return dispatch_tail_f32(a, act, res, s);

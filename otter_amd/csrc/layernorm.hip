@@ -1,6 +1,6 @@
 // Row-wise LayerNorm kernels (memory-bound): one 64-lane wave per row, the row held in registers,
 // 16-byte loads/stores, two-pass mean/variance in fp32 (matches torch.nn.LayerNorm numerics),
-// output bf16 (the next GEMM's A operand) or fp32 (the residual stream).
+// input fp32 or a 16-bit type (the residual stream), output a 16-bit type (the next GEMM's A operand) or fp32.
 //
 // Three row sources share the kernel:
 //   SRC_PLAIN   x[row]                                   (ln_1 / ln_2 / ln_post / ln_final / policy LNs)
@@ -14,7 +14,7 @@ namespace {
 enum { SRC_PLAIN = 0, SRC_VIT = 1, SRC_TEXT = 2 };
 
 struct LnArgs {
-    const float* x; long ldx;
+    const void* x; long ldx;             // fp32, or (SRC_PLAIN only) bf16 / fp16
     const float* gamma; const float* beta;
     void* y; long ldy;
     int rows, width; float eps;
@@ -24,25 +24,26 @@ struct LnArgs {
     const int* ids; int ctx, take, vocab;                 // row = b*take + t reads ids[b*ctx + t]
 };
 
-template <int NV, int SRC, int OUT_DT, bool NORMALISE>
+template <int NV, int SRC, int IN_DT, int OUT_DT, bool NORMALISE>
 __global__ __launch_bounds__(256) void ln_rows(LnArgs p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const int nvec = p.width >> 2;
 
-    const float* src;
+    static_assert(IN_DT == DT_F32 || SRC == SRC_PLAIN, "16-bit input: plain rows only");
+    const float* src = nullptr;
     const float* add = nullptr;
     if (SRC == SRC_PLAIN) {
-        src = p.x + (long)row * p.ldx;
+        if (IN_DT == DT_F32) src = (const float*)p.x + (long)row * p.ldx;
     } else if (SRC == SRC_VIT) {
         const int img = row / p.tokens, t = row % p.tokens;
-        src = (t == 0) ? p.cls : p.x + ((long)img * (p.tokens - 1) + (t - 1)) * p.ldx;
+        src = (t == 0) ? p.cls : (const float*)p.x + ((long)img * (p.tokens - 1) + (t - 1)) * p.ldx;
         add = p.pos + (long)t * p.width;
     } else {
         const int b = row / p.take, t = row % p.take;
         const int id = min(max(p.ids[(long)b * p.ctx + t], 0), p.vocab - 1);   // never index outside the table
-        src = p.x + (long)id * p.ldx;
+        src = (const float*)p.x + (long)id * p.ldx;
         add = p.pos + (long)t * p.width;
     }
 
@@ -53,7 +54,17 @@ __global__ __launch_bounds__(256) void ln_rows(LnArgs p) {
         const int idx = i * 64 + lane;
         v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (idx < nvec) {
-            v[i] = *(const f32x4*)(src + idx * 4);
+            if constexpr (IN_DT == DT_BF16) {
+                const bf16x4 h = *(const bf16x4*)((const __bf16*)p.x + (long)row * p.ldx + idx * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = (float)h[e];
+            } else if constexpr (IN_DT == DT_F16) {
+                const f16x4 h = *(const f16x4*)((const _Float16*)p.x + (long)row * p.ldx + idx * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = (float)h[e];
+            } else {
+                v[i] = *(const f32x4*)(src + idx * 4);
+            }
             if (SRC != SRC_PLAIN) v[i] += *(const f32x4*)(add + idx * 4);
             sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
@@ -97,13 +108,22 @@ __global__ __launch_bounds__(256) void ln_rows(LnArgs p) {
     }
 }
 
-template <int SRC, int OUT_DT, bool NORMALISE>
+template <int SRC, int IN_DT, int OUT_DT, bool NORMALISE>
 int launch_ln(const LnArgs& a, hipStream_t s, const char* name) {
     const int grid = (a.rows + 3) / 4;
-    if (a.width <= 1024) hipLaunchKernelGGL((ln_rows<4, SRC, OUT_DT, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((ln_rows<16, SRC, OUT_DT, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
+    if (a.width <= 1024) hipLaunchKernelGGL((ln_rows<4, SRC, IN_DT, OUT_DT, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_rows<16, SRC, IN_DT, OUT_DT, NORMALISE>), dim3(grid), dim3(256), 0, s, a);
     OTTER_CHECK_LAUNCH(name);
     return OTTER_OK;
+}
+
+template <int SRC, int IN_DT, bool NORMALISE>
+int launch_ln_out(const LnArgs& a, int out_dtype, hipStream_t s, const char* name) {
+    if (out_dtype == DT_F32) return launch_ln<SRC, IN_DT, DT_F32, NORMALISE>(a, s, name);
+    if (out_dtype == DT_BF16) return launch_ln<SRC, IN_DT, DT_BF16, NORMALISE>(a, s, name);
+    if (out_dtype == DT_F16) return launch_ln<SRC, IN_DT, DT_F16, NORMALISE>(a, s, name);
+    otter_set_error("%s: unknown out_dtype %d", name, out_dtype);
+    return OTTER_ERR_INVALID_ARGUMENT;
 }
 
 int check_width(int width, const char* name) {
@@ -114,7 +134,7 @@ int check_width(int width, const char* name) {
 
 }  // namespace
 
-extern "C" int otter_layernorm(const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+extern "C" int otter_layernorm(const void* x, int in_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
                                int rows, int width, float eps, int out_dtype, void* stream) {
     OTTER_REQUIRE(x && y && ((gamma == nullptr) == (beta == nullptr)), OTTER_ERR_INVALID_ARGUMENT,
                   "otter_layernorm: null operand (gamma and beta must both be given or both be NULL)");
@@ -128,16 +148,16 @@ extern "C" int otter_layernorm(const float* x, long ldx, const float* gamma, con
     LnArgs a{};
     a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.y = y; a.ldy = ldy; a.rows = rows; a.width = width; a.eps = eps;
     hipStream_t s = (hipStream_t)stream;
-    if (out_dtype == DT_F32) return launch_ln<SRC_PLAIN, DT_F32, true>(a, s, "otter_layernorm");
-    if (out_dtype == DT_BF16) return launch_ln<SRC_PLAIN, DT_BF16, true>(a, s, "otter_layernorm");
-    if (out_dtype == DT_F16) return launch_ln<SRC_PLAIN, DT_F16, true>(a, s, "otter_layernorm");
-    otter_set_error("otter_layernorm: unknown out_dtype %d", out_dtype);
+    if (in_dtype == DT_F32) return launch_ln_out<SRC_PLAIN, DT_F32, true>(a, out_dtype, s, "otter_layernorm");
+    if (in_dtype == DT_BF16) return launch_ln_out<SRC_PLAIN, DT_BF16, true>(a, out_dtype, s, "otter_layernorm");
+    if (in_dtype == DT_F16) return launch_ln_out<SRC_PLAIN, DT_F16, true>(a, out_dtype, s, "otter_layernorm");
+    otter_set_error("otter_layernorm: unknown in_dtype %d", in_dtype);
     return OTTER_ERR_INVALID_ARGUMENT;
 }
 
 extern "C" int otter_vit_embed_lnpre(const float* patch_tok, long ld_tok, const float* class_embedding, const float* pos_embedding,
-                                     const float* gamma, const float* beta, float* x, long ldx, int n_img, int n_patches,
-                                     int width, float eps, void* stream) {
+                                     const float* gamma, const float* beta, void* x, int out_dtype, long ldx, int n_img,
+                                     int n_patches, int width, float eps, void* stream) {
     OTTER_REQUIRE(patch_tok && class_embedding && pos_embedding && gamma && beta && x, OTTER_ERR_INVALID_ARGUMENT,
                   "otter_vit_embed_lnpre: null operand");
     if (n_img == 0) return OTTER_OK;
@@ -151,11 +171,11 @@ extern "C" int otter_vit_embed_lnpre(const float* patch_tok, long ld_tok, const 
     a.x = patch_tok; a.ldx = ld_tok; a.gamma = gamma; a.beta = beta; a.y = x; a.ldy = ldx;
     a.rows = n_img * (n_patches + 1); a.width = width; a.eps = eps;
     a.cls = class_embedding; a.pos = pos_embedding; a.tokens = n_patches + 1;
-    return launch_ln<SRC_VIT, DT_F32, true>(a, (hipStream_t)stream, "otter_vit_embed_lnpre");
+    return launch_ln_out<SRC_VIT, DT_F32, true>(a, out_dtype, (hipStream_t)stream, "otter_vit_embed_lnpre");
 }
 
 extern "C" int otter_text_embed(const int* ids, int ctx, int take, const float* token_embedding, int vocab,
-                                const float* pos_embedding, float* x, long ldx, int batch, int width, void* stream) {
+                                const float* pos_embedding, void* x, int out_dtype, long ldx, int batch, int width, void* stream) {
     OTTER_REQUIRE(ids && token_embedding && pos_embedding && x, OTTER_ERR_INVALID_ARGUMENT, "otter_text_embed: null operand");
     if (batch == 0) return OTTER_OK;
     OTTER_REQUIRE(batch > 0 && take > 0 && take <= ctx && vocab > 0, OTTER_ERR_INVALID_ARGUMENT,
@@ -167,5 +187,5 @@ extern "C" int otter_text_embed(const int* ids, int ctx, int take, const float* 
     LnArgs a{};
     a.x = token_embedding; a.ldx = width; a.y = x; a.ldy = ldx; a.rows = batch * take; a.width = width;
     a.pos = pos_embedding; a.ids = ids; a.ctx = ctx; a.take = take; a.vocab = vocab;
-    return launch_ln<SRC_TEXT, DT_F32, false>(a, (hipStream_t)stream, "otter_text_embed");
+    return launch_ln_out<SRC_TEXT, DT_F32, false>(a, out_dtype, (hipStream_t)stream, "otter_text_embed");
 }

@@ -45,21 +45,6 @@ __device__ __forceinline__ int f_swz(int r) {
     return (((lo + 4 * hi) & 7) << 1) | hi;
 }
 
-// reductions over the four 16-lane rows of a wave (same lane index li in every row) with v_permlane{32,16}_swap: VALU only,
-// no LDS round trip.  Every lane ends up with the result.
-__device__ __forceinline__ float rows_max(float v) {
-    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-__device__ __forceinline__ float rows_sum(float v) {
-    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 // NW waves per workgroup: each reduces D/NW columns of the similarity product and owns D/NW output columns (NDTW d-tiles
 // of 16).  NST = patch-tile buffers in LDS (prefetch distance NST-1 tiles).  WGS = workgroups the register budget lets
 // share a CU: the waves of co-resident workgroups overlap each other's dependent chains.

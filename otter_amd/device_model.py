@@ -4,9 +4,11 @@ Everything here enqueues HIP kernels from ``libotter_hip.so`` through :mod:`otte
 supplies device memory and the stream.  The arithmetic follows the reference's module tree
 (``otter/policy/otter.py:177-337``), restructured for the device:
 
-* CLIP towers: the fp32 residual stream stays in HBM, every GEMM / attention operand is a 16-bit type (bf16 or
-  fp16, fp32 accumulation), LayerNorm feeds the next GEMM directly in that type, bias / activation / residual-add
-  are GEMM epilogues;
+* CLIP towers: every GEMM / attention operand is a 16-bit type (bf16 or fp16, fp32 accumulation), LayerNorm feeds
+  the next GEMM directly in that type, bias / activation / residual-add are GEMM epilogues.  The residual stream
+  stays in HBM: in fp16 with fp16 towers (what the reference's own GPU path carries -- ``clip.load`` converts the
+  model to fp16 -- at half the bytes of the largest memory stream of the step), in fp32 with bf16 towers (8
+  mantissa bits are too few for a stream that accumulates 47 updates);
 * everything after the towers (pooling projections, input projection, policy, action head) is <0.5 % of the
   FLOPs and runs on the fp32 MFMA path so that actions track an fp32 reference to ~1e-4;
 * the last vision block stops after its attention out-projection (the reference hooks that activation and
@@ -69,10 +71,13 @@ class ClipDevice:
     """Frozen CLIP towers as OTTER uses them (``otter.py:177-222``)."""
 
     def __init__(self, sd: Dict[str, Tensor], arch: ClipArch, first_k: int, device, dtype=torch.float16,
-                 prefix: str = "clip_model."):
+                 prefix: str = "clip_model.", stream_dtype=None):
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError(f"CLIP tower operand dtype must be float16 or bfloat16, got {dtype}")
         self.arch, self.first_k, self.device, self.dtype = arch, first_k, device, dtype
+        self.stream_dtype = stream_dtype if stream_dtype is not None else (torch.float16 if dtype == torch.float16 else torch.float32)
+        if self.stream_dtype not in (torch.float32, dtype):
+            raise ValueError(f"residual stream dtype must be float32 or {dtype}, got {self.stream_dtype}")
         v = prefix + "visual."
         self.act = ops.ACT_QUICKGELU if arch.activation == "quick_gelu" else ops.ACT_GELU
         conv = sd[v + "conv1.weight"].float()
@@ -130,7 +135,7 @@ class ClipDevice:
             raise ValueError(f"image size {res} gives {p} patches, positional embedding has {self.vpos.shape[0] - 1}")
         cols = ops.im2col_patches(images, self.patch, self.k_im2col, CLIP_MEAN, CLIP_STD, self.dtype)
         tok = ops.gemm(cols, self.w_conv, self.vw, None, out_f32=True)
-        x = ops.vit_embed_lnpre(tok, self.cls, self.vpos, self.ln_pre[0], self.ln_pre[1], n, p)
+        x = ops.vit_embed_lnpre(tok, self.cls, self.vpos, self.ln_pre[0], self.ln_pre[1], n, p, out_dtype=self.stream_dtype)
         last = self._run_blocks(x, self.vblocks, n, p + 1, self.v_heads, False, True)
         h = ops.layernorm(last, *self.ln_post, out_dtype=self.dtype)
         feats = ops.gemm(h, self.w_vproj, self.embed, None)
@@ -152,7 +157,7 @@ class ClipDevice:
         if pooled_row:
             eot = ids.argmax(dim=-1)                                   # end-of-text has the highest id (49407)
             take = max(k, int(eot.max().item()) + 1)
-        x = ops.text_embed(ids, take, self.tok_emb, self.tpos)
+        x = ops.text_embed(ids, take, self.tok_emb, self.tpos, out_dtype=self.stream_dtype)
         x = self._run_blocks(x, self.tblocks, b, take, self.t_heads, True, False)
         h = ops.layernorm(x, *self.ln_final, out_dtype=self.dtype)
         feats = ops.gemm(h, self.w_tproj, self.embed, None, out_f32=True).view(b, take, self.embed)

@@ -81,7 +81,8 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
          out_f32: bool = False, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
          force_tile_128: bool = False) -> Tensor:
     """out[M, n] = epilogue(a[M, K] @ w[n, K]^T + bias); operands bf16 / fp16 / fp32 (``w_packed`` from
-    :func:`pack_weight` with the same dtype); output the operand type, or fp32 (``out_f32``, residual, fp32 operands)."""
+    :func:`pack_weight` with the same dtype); output the operand type, or fp32 (``out_f32``, an fp32 residual, fp32
+    operands).  ``residual`` (fp32, or the operands' 16-bit type) is added after the bias and fixes the output type."""
     dt = _dt(a.dtype, "gemm.a")
     _chk(a, a.dtype, "gemm.a")
     _chk(w_packed, a.dtype, "gemm.w", 2)
@@ -94,7 +95,9 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         _chk(bias, torch.float32, "gemm.bias", 1)
         if bias.numel() < n:
             raise ValueError("gemm: bias shorter than N")
-    f32_out = out_f32 or residual is not None or a.dtype == torch.float32
+    if residual is not None and residual.dtype not in (torch.float32, a.dtype):
+        raise ValueError(f"gemm.residual: {residual.dtype}, expected float32 or {a.dtype}")
+    f32_out = out_f32 or (residual is not None and residual.dtype == torch.float32) or a.dtype == torch.float32
     epi = act | (OUT_F32 if f32_out else 0) | (RESIDUAL if residual is not None else 0) | (TILE_128 if force_tile_128 else 0)
     odt = torch.float32 if f32_out else a.dtype
     if out is None:
@@ -105,7 +108,7 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         raise ValueError(f"gemm: out is {tuple(out.shape)}, expected ({m}, {n})")
     ldr = 0
     if residual is not None:
-        _chk(residual, torch.float32, "gemm.residual")
+        _chk(residual, odt, "gemm.residual")
         mr, nr, ldr = _rows_view(residual, "gemm.residual")
         if mr != m or nr != n:
             raise ValueError("gemm: residual shape mismatch")
@@ -118,7 +121,8 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
 
 def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], *, eps: float = 1e-5,
               out_dtype=torch.bfloat16, out: Optional[Tensor] = None) -> Tensor:
-    _chk(x, torch.float32, "layernorm.x")
+    _chk(x, x.dtype, "layernorm.x")
+    idt = _dt(x.dtype, "layernorm.x")
     rows, width, ldx = _rows_view(x, "layernorm.x")
     for t, nm in ((gamma, "gamma"), (beta, "beta")):
         if t is not None:
@@ -135,12 +139,12 @@ def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], *, eps
         raise ValueError("layernorm: out shape mismatch")
     if rows == 0:
         return out
-    _lib.call("otter_layernorm", _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(out), ldy, rows, width, eps, dt, _stream())
+    _lib.call("otter_layernorm", _ptr(x), idt, ldx, _ptr(gamma), _ptr(beta), _ptr(out), ldy, rows, width, eps, dt, _stream())
     return out
 
 
 def vit_embed_lnpre(patch_tok: Tensor, cls: Tensor, pos: Tensor, gamma: Tensor, beta: Tensor, n_img: int, n_patches: int,
-                    eps: float = 1e-5) -> Tensor:
+                    eps: float = 1e-5, out_dtype=torch.float32) -> Tensor:
     _chk(patch_tok, torch.float32, "vit_embed.patch_tok", 2)
     rows, width, ld = _rows_view(patch_tok, "vit_embed.patch_tok")
     if rows != n_img * n_patches:
@@ -153,13 +157,14 @@ def vit_embed_lnpre(patch_tok: Tensor, cls: Tensor, pos: Tensor, gamma: Tensor, 
         _chk(t, torch.float32, "vit_embed.ln", 1)
         if t.numel() != width:
             raise ValueError("vit_embed: ln_pre width mismatch")
-    x = torch.empty(n_img * (n_patches + 1), width, dtype=torch.float32, device=patch_tok.device)
-    _lib.call("otter_vit_embed_lnpre", _ptr(patch_tok), ld, _ptr(cls), _ptr(pos), _ptr(gamma), _ptr(beta), _ptr(x), width,
+    x = torch.empty(n_img * (n_patches + 1), width, dtype=out_dtype, device=patch_tok.device)
+    _lib.call("otter_vit_embed_lnpre", _ptr(patch_tok), ld, _ptr(cls), _ptr(pos), _ptr(gamma), _ptr(beta), _ptr(x),
+              _dt(out_dtype, "vit_embed.out_dtype"), width,
               n_img, n_patches, width, eps, _stream())
     return x
 
 
-def text_embed(ids: Tensor, take: int, token_embedding: Tensor, pos: Tensor) -> Tensor:
+def text_embed(ids: Tensor, take: int, token_embedding: Tensor, pos: Tensor, out_dtype=torch.float32) -> Tensor:
     _chk(ids, torch.int32, "text_embed.ids", 2)
     if not ids.is_contiguous():
         raise ValueError("text_embed.ids must be contiguous")
@@ -171,8 +176,9 @@ def text_embed(ids: Tensor, take: int, token_embedding: Tensor, pos: Tensor) -> 
         raise ValueError("text_embed: table/positional embedding shape mismatch")
     if not (0 < take <= ctx):
         raise ValueError(f"text_embed: take={take} outside 1..{ctx}")
-    x = torch.empty(b * take, width, dtype=torch.float32, device=ids.device)
-    _lib.call("otter_text_embed", _ptr(ids), ctx, take, _ptr(token_embedding), vocab, _ptr(pos), _ptr(x), width, b, width, _stream())
+    x = torch.empty(b * take, width, dtype=out_dtype, device=ids.device)
+    _lib.call("otter_text_embed", _ptr(ids), ctx, take, _ptr(token_embedding), vocab, _ptr(pos), _ptr(x), _dt(out_dtype, "text_embed.out_dtype"),
+              width, b, width, _stream())
     return x
 
 

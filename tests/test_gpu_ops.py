@@ -95,6 +95,28 @@ def test_gemm_128_tile_kernel(dev, m, n, k, dtype):
         assert torch.equal(out, ref)              # same products, same fp32 accumulation order along K
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("m,n,k", [(300, 256, 128), (32896 // 8, 1024, 1024), (130, 64, 64)])
+def test_gemm_residual_in_operand_type(dev, m, n, k, dtype):
+    """16-bit residual stream: out = round16(a @ w^T + bias + residual), in place, on all three kernels."""
+    from otter_amd import ops
+    dt = DTYPES[dtype]
+    a = _randn(31, m, k).to(dev).to(dt)
+    w = (_randn(32, n, k) / math.sqrt(k)).to(dev)
+    bias = _randn(33, n).to(dev)
+    wp = ops.pack_weight(w, dt)
+    x = (_randn(34, m, n) * 2).to(dev).to(dt)
+    ref = a.float() @ w.to(dt).float().t() + bias + x.float()
+    for kw in ({}, dict(force_tile_128=True)):
+        xs = x.clone()
+        out = ops.gemm(a, wp, n, bias, residual=xs, out=xs, **kw)
+        assert out.dtype == dt and out.data_ptr() == xs.data_ptr()
+        tol = 2e-2 if dtype == "bf16" else 3e-3                          # one rounding of |out| <~ 8 to the 16-bit type
+        torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)
+    with pytest.raises(ValueError):
+        ops.gemm(a, wp, n, bias, residual=x.to(torch.float16 if dt == torch.bfloat16 else torch.bfloat16))
+
+
 @pytest.mark.parametrize("m", [777, 1300])          # 128-row tiles only / 256-row tiles plus a 128-row-tile remainder
 def test_gemm_residual_strided_inplace(dev, m):
     from otter_amd import ops
@@ -142,6 +164,10 @@ def test_layernorm(dev, rows, width, dtype):
     torch.testing.assert_close(y.float(), ref, rtol=tol, atol=tol)
     y2 = ops.layernorm(x, None, None, out_dtype=torch.float32)
     torch.testing.assert_close(y2, torch.nn.functional.layer_norm(x, (width,)), rtol=1e-5, atol=1e-5)
+    if dtype != "f32":                                                     # 16-bit input (residual stream): statistics in fp32
+        x16 = x.to(DTYPES[dtype])
+        y3 = ops.layernorm(x16, g, b, out_dtype=torch.float32)
+        torch.testing.assert_close(y3, torch.nn.functional.layer_norm(x16.float(), (width,), g, b, 1e-5), rtol=1e-5, atol=1e-5)
 
 
 def test_vit_embed_and_text_embed(dev):

@@ -114,7 +114,11 @@ __device__ __forceinline__ float rows_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// x * sigmoid(1.702 x) with the hardware 2^x and reciprocal (1 ulp each; the IEEE division the plain expression compiles to
+// costs 10 instructions per element, 8 % of a 256x256x1024 GEMM tile)
+__device__ __forceinline__ float quick_gelu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896341f * x));
+}
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // Bijective remap of a linear workgroup id so that each of the 8 XCDs (which receive workgroups

@@ -70,10 +70,12 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     const int nkt = p.K / 64;
     int m0, n0;
     unsigned a_off[2][2], w_off[2][2];      // LDS-DMA source offsets (bytes from A / W): [half][instruction]
-    // Tile `t` of the launch order -> (m0, n0) and the per-thread source offsets of its half-tiles.  Image row lr
-    // of a W half-tile holds the weight row the MFMA fragment order wants there: fragment row (nt, i) of a wave's
-    // 32 columns is column 8*(i>>2) + 4*nt + (i&3), so a lane's accumulators of the two n-tiles are 8 CONSECUTIVE
-    // output columns (one 16-byte store for 16-bit outputs, two for fp32).
+    // Tile `t` of the launch order -> (m0, n0) and the per-thread source offsets of its half-tiles.  The accumulator of
+    // an (m-tile, n-tile) pair holds C[16mt + 4g + r][column li of the n-tile] in register r of lane (g, li).  Image row
+    // (n-tile nt, i) of half x of a wave's 64 columns is given the weight row of column 4i + 2x + nt, so the four n-tiles
+    // of a lane are 4 CONSECUTIVE output columns: the 16 lanes of a group store one contiguous 128-byte (16-bit output) or
+    // 256-byte (fp32) piece of a row, every quad of lanes a contiguous part of it (stores whose quads touch four rows
+    // take four times as long in the address unit).
     auto set_tile = [&](int t) {
         const int pid = xcd_remap(t, nwg);
         const int width = GROUP_M256 * p.tiles_n;
@@ -86,12 +88,12 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
             const int lr = (wave * 2 + i) * 8 + (lane >> 3);            // local row inside the half-tile image
             const int c = (lane & 7) ^ ((lr >> 1) & 7);
             const int fi = lr & 15, fnt = (lr >> 4) & 1;
-            const int wcol = (lr >> 5) * 64 + 8 * (fi >> 2) + 4 * fnt + (fi & 3);
+            const int wcol = (lr >> 5) * 64 + 4 * fi + fnt;
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const int trow = (lr < 64 ? lr : lr + 64) + x * 64;      // A: tile row
                 a_off[x][i] = (unsigned)(m0 + trow) * (unsigned)(p.lda * 2) + c * 16;
-                w_off[x][i] = (unsigned)(n0 + wcol + x * 32) * (unsigned)(p.K * 2) + c * 16;
+                w_off[x][i] = (unsigned)(n0 + wcol + x * 2) * (unsigned)(p.K * 2) + c * 16;
             }
         }
     };
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                   \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                               \
-                acc[S][X][mt][nt] = Half16<T>::mfma32(bf[nt][ks], af[mt][ks], acc[S][X][mt][nt]);
+                acc[S][X][mt][nt] = Half16<T>::mfma32(af[mt][ks], bf[nt][ks], acc[S][X][mt][nt]);
 
     // Two wave groups (waves 0-3 / 4-7; each SIMD hosts one wave of each) run the same program one barrier apart:
     // while one group is in a load segment (LDS fragment reads + LDS-DMA issue) the other is in its MFMA segment,
@@ -238,55 +240,56 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
         set_tile(tile);
         issue_prologue();
     }
-    // accumulator tile = D[row n][col m]; lane holds m = li and, over its two n-tiles, columns 8g + 0..7
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        const int n = cn0 + wc * 64 + x * 32 + g * 8;
+    // lane (g, li): rows 16mt + 4g + r, columns 4li + 0..3 of the wave's 64
+    {
+        const int n = cn0 + wc * 64 + 4 * li;
         if (n < p.N) {
-            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-                b0 = *(const f32x4*)(p.bias + n);
-                b1 = *(const f32x4*)(p.bias + n + 4);
-            }
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s) {
+                // The residual is usually the output buffer itself, so the compiler must keep every load ahead of the next
+                // store and, loads and stores retiring in order, would wait out one memory round trip per row: fetch the
+                // residual of 16 rows first, then store the 16 rows.
+                typedef typename Half16<T>::v4 h4;
+                f32x4 rf[RES && OUT_F32 ? 16 : 1];
+                h4 rh[RES && !OUT_F32 ? 16 : 1];
+                if (RES) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const int m = cm0 + wr * 128 + s * 64 + mt * 16 + li;
-                    f32x4 v0 = acc[s][x][mt][0] + b0, v1 = acc[s][x][mt][1] + b1;
+                    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v0[e] = act256<ACT>(v0[e]);
-                        v1[e] = act256<ACT>(v1[e]);
-                    }
-                    if (RES) {
-                        if constexpr (OUT_F32) {
-                            const float* r = (const float*)p.residual + (long)m * p.ldr + n;
-                            v0 += *(const f32x4*)r;
-                            v1 += *(const f32x4*)(r + 4);
-                        } else {
-                            const typename Half16<T>::v8 r = *(const typename Half16<T>::v8*)((const T*)p.residual + (long)m * p.ldr + n);
+                        for (int r = 0; r < 4; ++r) {
+                            const long off = (long)(cm0 + wr * 128 + s * 64 + mt * 16 + 4 * g + r) * p.ldr + n;
+                            if constexpr (OUT_F32) rf[mt * 4 + r] = *(const f32x4*)((const float*)p.residual + off);
+                            else rh[mt * 4 + r] = *(const h4*)((const T*)p.residual + off);
+                        }
+                }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v0[e] += (float)r[e];
-                                v1[e] += (float)r[4 + e];
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = cm0 + wr * 128 + s * 64 + mt * 16 + 4 * g + r;
+                        f32x4 v = (f32x4){acc[s][0][mt][0][r], acc[s][0][mt][1][r], acc[s][1][mt][0][r], acc[s][1][mt][1][r]} + bv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act256<ACT>(v[e]);
+                        if (RES) {
+                            if constexpr (OUT_F32) {
+                                v += rf[mt * 4 + r];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)rh[mt * 4 + r][e];
                             }
                         }
-                    }
-                    if constexpr (OUT_F32) {
-                        float* c = (float*)p.C + (long)m * p.ldc + n;
-                        *(f32x4*)c = v0;
-                        *(f32x4*)(c + 4) = v1;
-                    } else {
-                        typename Half16<T>::v8 o;
+                        if constexpr (OUT_F32) {
+                            *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
+                        } else {
+                            h4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            o[e] = Half16<T>::from(v0[e]);
-                            o[4 + e] = Half16<T>::from(v1[e]);
+                            for (int e = 0; e < 4; ++e) o[e] = Half16<T>::from(v[e]);
+                            *(h4*)((T*)p.C + (long)m * p.ldc + n) = o;
                         }
-                        *(typename Half16<T>::v8*)((T*)p.C + (long)m * p.ldc + n) = o;
                     }
-                }
+            }
         }
     }
     if (!more) break;
@@ -344,7 +347,7 @@ int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, hipStream
 bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc) {
     if (dtype != DT_BF16 && dtype != DT_F16) return false;
     if (M < 1024 || N < 256 || K % 64 != 0) return false;                       // small problems: 128x128 tiles fill the chip better
-    if (N % 8 != 0 || ldc % 8 != 0 || ((uintptr_t)C & 15) != 0) return false;     // a lane stores 8 consecutive columns as 16-byte vectors
+    if (N % 8 != 0 || ldc % 8 != 0 || ((uintptr_t)C & 15) != 0) return false;     // a lane stores 4 consecutive columns as one vector; rows stay 16-byte aligned
     if (n_pad < ((N + TN - 1) / TN) * TN) return false;                          // weight rows must cover whole 256-column tiles
     if ((long)(M / TM) * ((N + TN - 1) / TN) < 128) return false;                // fewer tiles than half the CUs: smaller tiles fill the chip better
     if ((long)M * lda * 2 >= (1L << 32) || (long)n_pad * K * 2 >= (1L << 32)) return false;   // 32-bit source offsets

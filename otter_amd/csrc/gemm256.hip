@@ -4,26 +4,24 @@
 //
 // One workgroup = 8 waves (2 along M x 4 along N) works on one 256x256 output tile at a time, one persistent
 // workgroup per CU looping over tiles (M must be a multiple of 256: the caller routes remainder rows to the
-// 128x128 kernel); each wave
+// 64x64 kernel); each wave
 // owns 128(M) x 64(N) = 8x4 accumulator tiles of 16x16 (128 accumulator registers).  A K-step is 64 elements
 // (128 bytes per row).
 //
 // Data movement.  Each operand tile of a K-step is cut into two 16 KiB "half-tiles" (128 rows x 128 bytes):
 //   A_h0 = tile rows {0..63, 128..191}   A_h1 = tile rows {64..127, 192..255}
-//   B_h0 = tile cols {64c + 0..31}       B_h1 = tile cols {64c + 32..63}        (c = 0..3)
-// so that every wave's work splits into four quadrants q0=(A_h0,B_h0) q1=(A_h0,B_h1) q2=(A_h1,B_h1) q3=(A_h1,B_h0),
-// 16 MFMAs each, executed in that (snake) order: one phase per quadrant, each phase = a load segment (fragment
-// reads of the operand half that changed + one LDS-DMA half-tile issue) and an MFMA segment, separated by barriers.
+//   B_h0, B_h1 = the two 32-row halves of every wave column's 64 weight rows (which output columns those are: set_tile)
+// so that every wave's work splits into four quadrants (A_h0,B_h0) (A_h0,B_h1) (A_h1,B_h1) (A_h1,B_h0), 16 MFMAs each.
+// A K-step runs as two halves, one per A half-tile: a load segment (fragment reads of the A half -- and, in the
+// first half, of both B halves, which stay in registers -- plus LDS-DMA issues) and an MFMA segment of two quadrants,
+// separated by workgroup barriers (four per K-step).
 // LDS holds two K-steps x four half-tile slots (128 KiB).  Half-tiles arrive by LDS-DMA (global_load_lds_dwordx4,
-// two instructions per thread per half-tile) and a slot is refilled as soon as its last reader phase is over:
-//   phase (t,0): A_h1(t+1)   (t,1): B_h0(t+1)   (t,2): A_h0(t+2)   (t,3): B_h1(t+2)
-// Every load therefore has 3..6 phases (>= 768 MFMA cycles) to land, and only ONE counted wait per K-step is
-// needed: s_waitcnt vmcnt(4) at the end of phase 3 leaves the two youngest half-tiles in flight and guarantees
+// two instructions per thread per half-tile) and a slot is refilled as soon as its last reader segment is over:
+//   first load segment of K-step t: A_h1(t+1)      second: A_h0(t+2), B_h0(t+2), B_h1(t+2)
+// Every load therefore has more than a K-step (>= 2048 MFMA cycles) to land, and only ONE counted wait per K-step is
+// needed: s_waitcnt vmcnt(6) at the end of the K-step leaves the six youngest requests in flight and guarantees
 // that all of K-step t+1 has landed (the barrier that follows publishes it to the other waves).  The loop never
 // drains the memory queue; raw s_barrier is used because __syncthreads() would add vmcnt(0).
-//
-// Write-after-read safety: a slot's refill is issued at least one barrier after the last phase that reads it
-// (A_h0: read in phases 0,1 -> refilled in phase 2; B_h1: 1,2 -> 3; A_h1: 2,3 -> next phase 0; B_h0: 0,3 -> next 1).
 //
 // LDS images are lane-linear (LDS-DMA requirement) with the 16-byte chunk index XOR-swizzled on the source
 // address and on the ds_read_b128 address, as in gemm.hip.
@@ -110,14 +108,15 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + i * 1024), 16, 0, 0);
         }
     };
-    // K-step 0 completely, plus the two half-tiles of K-step 1 that phases (-1,2) and (-1,3) would issue
+    // K-step 0 completely, plus the three half-tiles of K-step 1 that the second half of K-step -1 would issue
     auto issue_prologue = [&]() {
         issue(0, SLOT_A0, 0);
+        issue(0, SLOT_B0, 0);
         issue(0, SLOT_B1, 0);
         issue(0, SLOT_A1, 0);
-        issue(0, SLOT_B0, 0);
         if (nkt > 1) {
             issue(1, SLOT_A0, 1);
+            issue(1, SLOT_B0, 1);
             issue(1, SLOT_B1, 1);
         }
     };
@@ -151,12 +150,12 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                 for (int nt = 0; nt < 2; ++nt) acc[s][x][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // first tile: the two youngest half-tiles may stay in flight; later tiles: the epilogue's stores were issued
     // after the prologue loads, so everything is drained
-    if (first && nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (first && nkt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     first = false;
     wg_barrier();
 
-    frag_t af[4][2], bf[2][2];
+    frag_t af[4][2], bf[2][2][2];               // A half in use; both B halves of the K-step: [half x][n-tile][k-sub-step]
     auto load_a = [&](int buf, int slot) {
         const char* base = smem + (buf * 4 + slot) * HALF_BYTES + a_row0;
 #pragma unroll
@@ -164,69 +163,66 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const frag_t*)(base + mt * 2048 + koff[ks]);
     };
-    auto load_b = [&](int buf, int slot) {
+    auto load_b = [&](int buf, int slot, int x) {
         const char* base = smem + (buf * 4 + slot) * HALF_BYTES + b_row0;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bf[nt][ks] = *(const frag_t*)(base + nt * 2048 + koff[ks]);
+            for (int ks = 0; ks < 2; ++ks) bf[x][nt][ks] = *(const frag_t*)(base + nt * 2048 + koff[ks]);
     };
 #define OTTER_QUADRANT(S, X)                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                   \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                               \
-                acc[S][X][mt][nt] = Half16<T>::mfma32(af[mt][ks], bf[nt][ks], acc[S][X][mt][nt]);
+                acc[S][X][mt][nt] = Half16<T>::mfma32(af[mt][ks], bf[X][nt][ks], acc[S][X][mt][nt]);
 
+    // A K-step is two halves, one per A half-tile: load segment (fragment reads + LDS-DMA issues) then MFMA segment (two
+    // quadrants = 32 MFMAs per wave), four workgroup barriers per K-step.  Both B halves are read in the first half
+    // and stay in registers for the second.
     // Two wave groups (waves 0-3 / 4-7; each SIMD hosts one wave of each) run the same program one barrier apart:
-    // while one group is in a load segment (LDS fragment reads + LDS-DMA issue) the other is in its MFMA segment,
-    // so the matrix pipe of every SIMD always has a wave feeding it.  Segments are separated by workgroup
-    // barriers; group 1 starts one barrier late and group 0 ends with one extra barrier.  The counted wait that
-    // retires K-step t+1 sits at the end of the same global segment for both groups (end of the MFMA segment of
-    // phase 3 for group 0, end of the load segment of phase 3 for group 1), one barrier before its first reader.
+    // while one group is in a load segment the other is in its MFMA segment, so the matrix pipe of every SIMD always has
+    // a wave feeding it.  Group 1 starts one barrier late and group 0 ends with one extra barrier.
+    // Slot refills (write after read): A_h0, B_h0, B_h1 of a buffer are last read in the first load segment, so their
+    // K-step t+2 contents are requested in the second one; A_h1 is last read in the second and refilled in the first
+    // load segment of K-step t+1.  K-step t+1 is therefore complete once at most the six requests of the second load
+    // segment of K-step t are outstanding: one counted wait per K-step, at the end of the same global segment for
+    // both groups, one barrier before the first reader.
 #define OTTER_SEG_END()                                     \
     __builtin_amdgcn_sched_barrier(0);                      \
     wg_barrier();                                           \
     __builtin_amdgcn_sched_barrier(0);
-#define OTTER_MFMA_SEG(S, X)                                \
+#define OTTER_MFMA_SEG2(S, X0, X1)                          \
     __builtin_amdgcn_s_setprio(1);                          \
-    OTTER_QUADRANT(S, X)                                    \
+    OTTER_QUADRANT(S, X0)                                   \
+    OTTER_QUADRANT(S, X1)                                   \
     __builtin_amdgcn_s_setprio(0);
 #define OTTER_RETIRE_NEXT()                                                       \
-    if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             \
+    if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");             \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (late) { OTTER_SEG_END() }
     for (int t = 0; t < nkt; ++t) {
         const int buf = t & 1;
-        // phase 0: q0 = (A_h0, B_h0)
+        // first half: (A_h0, B_h0), (A_h0, B_h1)
         load_a(buf, SLOT_A0);
-        load_b(buf, SLOT_B0);
+        load_b(buf, SLOT_B0, 0);
+        load_b(buf, SLOT_B1, 1);
         if (t + 1 < nkt) issue(buf ^ 1, SLOT_A1, t + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         OTTER_SEG_END()
-        OTTER_MFMA_SEG(0, 0)
+        OTTER_MFMA_SEG2(0, 0, 1)
         OTTER_SEG_END()
-        // phase 1: q1 = (A_h0, B_h1)
-        load_b(buf, SLOT_B1);
-        if (t + 1 < nkt) issue(buf ^ 1, SLOT_B0, t + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        OTTER_SEG_END()
-        OTTER_MFMA_SEG(0, 1)
-        OTTER_SEG_END()
-        // phase 2: q2 = (A_h1, B_h1)
+        // second half: (A_h1, B_h1), (A_h1, B_h0)
         load_a(buf, SLOT_A1);
-        if (t + 2 < nkt) issue(buf, SLOT_A0, t + 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        OTTER_SEG_END()
-        OTTER_MFMA_SEG(1, 1)
-        OTTER_SEG_END()
-        // phase 3: q3 = (A_h1, B_h0)
-        load_b(buf, SLOT_B0);
-        if (t + 2 < nkt) issue(buf, SLOT_B1, t + 2);
+        if (t + 2 < nkt) {
+            issue(buf, SLOT_A0, t + 2);
+            issue(buf, SLOT_B0, t + 2);
+            issue(buf, SLOT_B1, t + 2);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (late) { OTTER_RETIRE_NEXT() }
         OTTER_SEG_END()
-        OTTER_MFMA_SEG(1, 0)
+        OTTER_MFMA_SEG2(1, 1, 0)
         if (!late) { OTTER_RETIRE_NEXT() }
         OTTER_SEG_END()
     }
@@ -295,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     if (!more) break;
     }   // tile loop
 #undef OTTER_SEG_END
-#undef OTTER_MFMA_SEG
+#undef OTTER_MFMA_SEG2
 #undef OTTER_RETIRE_NEXT
 #undef OTTER_QUADRANT
 }

@@ -134,14 +134,15 @@ def measure_kernels(work, steps: int):
             return real_gemm(a, wp, n, bias, act=act, out_f32=out_f32, residual=residual, out=out, force_tile_128=force_tile_128)
         m_main = m // 256 * 256
         if out is None:
-            out = torch.empty(m, n, dtype=torch.float32 if (out_f32 or residual is not None) else a.dtype, device=a.device)
+            odt = residual.dtype if residual is not None else (torch.float32 if out_f32 else a.dtype)
+            out = torch.empty(m, n, dtype=odt, device=a.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         real_gemm(a[:m_main], wp, n, bias, act=act, out_f32=out_f32, residual=None if residual is None else residual[:m_main], out=out[:m_main])
         e1.record()
         k_real = 588 if kk == 640 else kk          # algorithmic FLOPs: the un-padded K of the patch embedding
-        out_bytes = 4 if (out_f32 or residual is not None) else 2
-        nbytes = m_main * kk * 2 + n * kk * 2 + m_main * n * out_bytes + (m_main * n * 4 if residual is not None else 0)
+        out_bytes = out.element_size()
+        nbytes = m_main * kk * 2 + n * kk * 2 + m_main * n * out_bytes + (m_main * n * residual.element_size() if residual is not None else 0)
         rec["gemm"].append((e0, e1, 2.0 * m_main * n * k_real, float(nbytes)))
         if m_main < m:
             real_gemm(a[m_main:], wp, n, bias, act=act, out_f32=out_f32, residual=None if residual is None else residual[m_main:], out=out[m_main:])

@@ -126,26 +126,30 @@ def measure_kernels(work, steps: int):
             return out
         return wrapper
 
-    def gemm_wrapper(a, wp, n, bias=None, *, act=0, out_f32=False, residual=None, out=None, force_tile_128=False):
+    def gemm_wrapper(a, wp, n, bias=None, *, act=0, out_f32=False, residual=None, out=None, force_tile_128=False,
+                     ln_stats=None, ln_colsum=None):
         """Times the dominant kernel only: a big 16-bit GEMM is issued as its whole 256-row tiles (the 256x256 kernel, timed)
         and its remainder rows (the 64x64 kernel, not timed) -- rows are independent, so the results are those of one call."""
         m, kk = a.shape
         if a.dtype == torch.float32 or m < 1024 or n < 256 or force_tile_128:
-            return real_gemm(a, wp, n, bias, act=act, out_f32=out_f32, residual=residual, out=out, force_tile_128=force_tile_128)
+            return real_gemm(a, wp, n, bias, act=act, out_f32=out_f32, residual=residual, out=out, force_tile_128=force_tile_128,
+                             ln_stats=ln_stats, ln_colsum=ln_colsum)
         m_main = m // 256 * 256
         if out is None:
             odt = residual.dtype if residual is not None else (torch.float32 if out_f32 else a.dtype)
             out = torch.empty(m, n, dtype=odt, device=a.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        real_gemm(a[:m_main], wp, n, bias, act=act, out_f32=out_f32, residual=None if residual is None else residual[:m_main], out=out[:m_main])
+        real_gemm(a[:m_main], wp, n, bias, act=act, out_f32=out_f32, residual=None if residual is None else residual[:m_main], out=out[:m_main],
+                  ln_stats=None if ln_stats is None else ln_stats[:m_main], ln_colsum=ln_colsum)
         e1.record()
         k_real = 588 if kk == 640 else kk          # algorithmic FLOPs: the un-padded K of the patch embedding
         out_bytes = out.element_size()
         nbytes = m_main * kk * 2 + n * kk * 2 + m_main * n * out_bytes + (m_main * n * residual.element_size() if residual is not None else 0)
         rec["gemm"].append((e0, e1, 2.0 * m_main * n * k_real, float(nbytes)))
         if m_main < m:
-            real_gemm(a[m_main:], wp, n, bias, act=act, out_f32=out_f32, residual=None if residual is None else residual[m_main:], out=out[m_main:])
+            real_gemm(a[m_main:], wp, n, bias, act=act, out_f32=out_f32, residual=None if residual is None else residual[m_main:], out=out[m_main:],
+                      ln_stats=None if ln_stats is None else ln_stats[m_main:], ln_colsum=ln_colsum)
         return out
 
     def tave_bytes(a, k, out):

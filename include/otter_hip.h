@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 6
+#define OTTER_HIP_ABI_VERSION 7
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -51,6 +51,17 @@ const char* otter_last_error(void);
  * action head (otter/policy/models.py:58-62), pooling k/v projections (transformer.py:165-171). */
 int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const void* residual,
                long ldr, void* C, long ldc, int M, int N, int K, int epilogue, void* stream);
+
+/* LayerNorm folded into the GEMM that consumes it (ln_1 -> in_proj and ln_2 -> c_fc of a CLIP resblock, reached from
+ * otter.py:189-190): with W' = W * gamma (column-wise), col_sum[n] = sum_k W'[n,k] (of the rounded 16-bit W') and
+ * bias' = bias + W . beta,
+ *   C[m,n] = act( rstd[m] * (A[m,:] . W'[n,:] - mean[m] * col_sum[n]) + bias'[n] )  ==  act(LayerNorm(A)[m,:] . W[n,:] + bias[n])
+ * so the GEMM reads the residual stream itself and the normalised copy is never written.  row_stats: [M][2] =
+ * (mean, rstd) from otter_row_stats; the other arguments as otter_gemm (no residual epilogue). */
+int otter_gemm_ln(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const float* row_stats,
+                  const float* col_sum, void* C, long ldc, int M, int N, int K, int epilogue, void* stream);
+/* stats[r] = (mean, 1/sqrt(var + eps)) of row r (two-pass, fp32), x fp32 or 16-bit. */
+int otter_row_stats(const void* x, int in_dtype, long ldx, float* stats, int rows, int width, float eps, void* stream);
 
 /* y[r,:] = LayerNorm(x[r,:]) * gamma + beta  (in_dtype / out_dtype = OTTER_DT_*: x may be the fp32 or the 16-bit
  * residual stream; statistics in fp32; gamma/beta NULL = no affine).

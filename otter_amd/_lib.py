@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
@@ -35,6 +35,8 @@ _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
 
 _SIGNATURES = {
     "otter_gemm": [_I, _P, _L, _P, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "otter_gemm_ln": [_I, _P, _L, _P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "otter_row_stats": [_P, _I, _L, _P, _I, _I, _F, _P],
     "otter_layernorm": [_P, _I, _L, _P, _P, _P, _L, _I, _I, _F, _I, _P],
     "otter_vit_embed_lnpre": [_P, _L, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P],
     "otter_text_embed": [_P, _I, _I, _P, _I, _P, _P, _I, _L, _I, _I, _P],

@@ -23,12 +23,14 @@
 // 256x256-tile kernel for the big 16-bit shapes (gemm256.hip)
 bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc);
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
-                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
+                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
+                         const float* ln_colsum, hipStream_t s);
 
 // 64x64-tile kernel for remainder rows and small problems (gemm_tail.hip)
 bool otter_gemm64_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc);
 int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
-                        void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s);
+                        void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
+                        const float* ln_colsum, hipStream_t s);
 
 namespace {
 
@@ -44,6 +46,8 @@ struct GemmArgs {
     const void* residual; long ldr;     // in the OUTPUT's type
     void* C; long ldc;
     int M, N, K, tiles_m, tiles_n;
+    const float* ln_stats;      // [M][2] (mean, rstd) or null: LayerNorm folded into the epilogue (see otter_gemm_ln)
+    const float* ln_colsum;     // [N]
 };
 
 enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU = 2, ACT_RELU = 3 };
@@ -153,13 +157,19 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128(GemmArgs p) {
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + wn * 64 + i * 16 + nq;
         if (n >= p.N) continue;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        f32x4 b = {0.f, 0.f, 0.f, 0.f}, cs = b;
         if (p.bias) b = *(const f32x4*)(p.bias + n);
+        if (p.ln_stats) cs = *(const f32x4*)(p.ln_colsum + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + wm * 64 + j * 16 + mc;
             if (m >= p.M) continue;
-            f32x4 v = acc[i][j] + b;
+            f32x4 v = acc[i][j];
+            if (p.ln_stats) {
+                const f32x2 st = *(const f32x2*)(p.ln_stats + 2 * (long)m);
+                v = (v - st[0] * cs) * st[1];
+            }
+            v += b;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e]);
             if (RES) {
@@ -224,9 +234,9 @@ int dispatch(const GemmArgs& a, int act, bool out_f32, bool res, hipStream_t s) 
 
 }  // namespace
 
-extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias,
-                          const void* residual, long ldr, void* C, long ldc, int M, int N, int K,
-                          int epilogue, void* stream) {
+static int gemm_impl(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias,
+                     const void* residual, long ldr, void* C, long ldc, int M, int N, int K,
+                     int epilogue, const float* ln_stats, const float* ln_colsum, void* stream) {
     OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16 || dtype == DT_F32, OTTER_ERR_INVALID_ARGUMENT, "otter_gemm: unknown dtype %d", dtype);
     const int es = dtype == DT_F32 ? 4 : 2;
     const int kq = ROW_BYTES / es;
@@ -250,23 +260,40 @@ extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int
         OTTER_REQUIRE(act == OTTER_EPI_ACT_NONE, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm: residual epilogue takes no activation");
     }
     hipStream_t s = (hipStream_t)stream;
-    if (!(epilogue & OTTER_EPI_TILE_128) && otter_gemm256_eligible(dtype, lda, n_pad, M, N, K, C, ldc)) {
+    // (the 256x256 kernel has the folded-LayerNorm epilogue for 16-bit outputs with no / QuickGELU / GELU activation only)
+    const bool ln256 = !ln_stats || (!out_f32 && act != OTTER_EPI_ACT_RELU);
+    if (!(epilogue & OTTER_EPI_TILE_128) && ln256 && otter_gemm256_eligible(dtype, lda, n_pad, M, N, K, C, ldc)) {
         // Rows are independent: whole 256-row tiles go to the 256x256 kernel, the remaining (< 256) rows to the
         // 64x64 kernel.
         const int m_main = (M / 256) * 256;
-        int rc = otter_gemm256_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, m_main, N, K, act, out_f32, res, s);
+        int rc = otter_gemm256_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, m_main, N, K, act, out_f32, res, ln_stats, ln_colsum, s);
         if (rc != OTTER_OK || m_main == M) return rc;
         const long ec = (out_f32 ? 4 : es);
         return otter_gemm64_launch(dtype, (const char*)A + (long)m_main * lda * es, lda, W, bias,
                                       res ? (const char*)residual + (long)m_main * ldr * ec : nullptr, ldr, (char*)C + (long)m_main * ldc * ec, ldc,
-                                      M - m_main, N, K, act, out_f32, res, s);
+                                      M - m_main, N, K, act, out_f32, res, ln_stats ? ln_stats + 2 * (long)m_main : nullptr, ln_colsum, s);
     }
     // too few 128x128 tiles to give every CU one: the 64x64 kernel spreads the problem over 4x more workgroups
     if (!(epilogue & OTTER_EPI_TILE_128) && (long)tiles_m * tiles_n < 256 && otter_gemm64_eligible(dtype, lda, n_pad, M, N, K, C, ldc))
-        return otter_gemm64_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, M, N, K, act, out_f32, res, s);
+        return otter_gemm64_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, M, N, K, act, out_f32, res, ln_stats, ln_colsum, s);
     const int tm = (M + BM - 1) / BM;
-    GemmArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, tm, tiles_n};
+    GemmArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, tm, tiles_n, ln_stats, ln_colsum};
     if (dtype == DT_BF16) return dispatch<__bf16>(a, act, out_f32, res, s);
     if (dtype == DT_F16) return dispatch<_Float16>(a, act, out_f32, res, s);
     return dispatch<float>(a, act, true, res, s);
+}
+
+extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias,
+                          const void* residual, long ldr, void* C, long ldc, int M, int N, int K,
+                          int epilogue, void* stream) {
+    return gemm_impl(dtype, A, lda, W, n_pad, bias, residual, ldr, C, ldc, M, N, K, epilogue, nullptr, nullptr, stream);
+}
+
+extern "C" int otter_gemm_ln(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias,
+                             const float* row_stats, const float* col_sum, void* C, long ldc, int M, int N, int K,
+                             int epilogue, void* stream) {
+    OTTER_REQUIRE(row_stats && col_sum && aligned16(col_sum) && (reinterpret_cast<uintptr_t>(row_stats) & 7u) == 0, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_gemm_ln: row_stats (8-byte aligned) and col_sum (16-byte aligned) are required");
+    OTTER_REQUIRE(!(epilogue & OTTER_EPI_RESIDUAL), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_ln: no residual epilogue");
+    return gemm_impl(dtype, A, lda, W, n_pad, bias, nullptr, 0, C, ldc, M, N, K, epilogue, row_stats, col_sum, stream);
 }

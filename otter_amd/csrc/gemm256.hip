@@ -42,6 +42,8 @@ struct Gemm256Args {
     const void* residual; long ldr;     // in the OUTPUT's type: fp32 with OUT_F32, else the 16-bit operand type
     void* C; long ldc;
     int M, N, K, tiles_m, tiles_n;
+    const float* ln_stats;      // [M][2] (mean, rstd) or null: LayerNorm folded into the epilogue (see otter_gemm_ln)
+    const float* ln_colsum;     // [N]
 };
 
 enum { SLOT_A0 = 0, SLOT_B0 = 1, SLOT_B1 = 2, SLOT_A1 = 3 };
@@ -56,7 +58,7 @@ template <int ACT> __device__ __forceinline__ float act256(float v) {
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <typename T, int ACT, bool OUT_F32, bool RES>
+template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false>      // LNF: LayerNorm folded into the epilogue (p.ln_stats)
 __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 frag_t;
@@ -240,8 +242,9 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     {
         const int n = cn0 + wc * 64 + 4 * li;
         if (n < p.N) {
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = bv;
             if (p.bias) bv = *(const f32x4*)(p.bias + n);
+            if (LNF) cs = *(const f32x4*)(p.ln_colsum + n);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // The residual is usually the output buffer itself, so the compiler must keep every load ahead of the next
@@ -250,6 +253,14 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                 typedef typename Half16<T>::v4 h4;
                 f32x4 rf[RES && OUT_F32 ? 16 : 1];
                 h4 rh[RES && !OUT_F32 ? 16 : 1];
+                f32x2 st[LNF ? 16 : 1];         // (mean, rstd) of the 16 rows, fetched ahead of the stores for the same reason
+                if (LNF) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            st[mt * 4 + r] = *(const f32x2*)(p.ln_stats + 2 * (long)(cm0 + wr * 128 + s * 64 + mt * 16 + 4 * g + r));
+                }
                 if (RES) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
@@ -265,7 +276,9 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int m = cm0 + wr * 128 + s * 64 + mt * 16 + 4 * g + r;
-                        f32x4 v = (f32x4){acc[s][0][mt][0][r], acc[s][0][mt][1][r], acc[s][1][mt][0][r], acc[s][1][mt][1][r]} + bv;
+                        f32x4 v = (f32x4){acc[s][0][mt][0][r], acc[s][0][mt][1][r], acc[s][1][mt][0][r], acc[s][1][mt][1][r]};
+                        if (LNF) v = (v - st[mt * 4 + r][0] * cs) * st[mt * 4 + r][1];
+                        v += bv;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = act256<ACT>(v[e]);
                         if (RES) {
@@ -296,9 +309,9 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
 #undef OTTER_QUADRANT
 }
 
-template <typename T, int ACT, bool OUT_F32, bool RES>
+template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false>
 int launch256(const Gemm256Args& a, hipStream_t s) {
-    auto kern = gemm_256x256<T, ACT, OUT_F32, RES>;
+    auto kern = gemm_256x256<T, ACT, OUT_F32, RES, LNF>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -327,6 +340,13 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
 template <typename T>
 int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, hipStream_t s) {
     if (res) return out_f32 ? launch256<T, ACT_NONE, true, true>(a, s) : launch256<T, ACT_NONE, false, true>(a, s);
+    if (a.ln_stats && !out_f32) {
+        switch (act) {
+            case OTTER_EPI_ACT_NONE: return launch256<T, ACT_NONE, false, false, true>(a, s);
+            case OTTER_EPI_ACT_QUICKGELU: return launch256<T, ACT_QUICKGELU, false, false, true>(a, s);
+            case OTTER_EPI_ACT_GELU: return launch256<T, ACT_GELU, false, false, true>(a, s);
+        }
+    }
     switch (act) {
         case OTTER_EPI_ACT_NONE: return out_f32 ? launch256<T, ACT_NONE, true, false>(a, s) : launch256<T, ACT_NONE, false, false>(a, s);
         case OTTER_EPI_ACT_QUICKGELU: return out_f32 ? launch256<T, ACT_QUICKGELU, true, false>(a, s) : launch256<T, ACT_QUICKGELU, false, false>(a, s);
@@ -351,11 +371,12 @@ bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K,
 }
 
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
-                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s) {
+                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
+                         const float* ln_colsum, hipStream_t s) {
     if (M <= 0 || M % TM != 0) {                     // whole 256-row tiles only: the caller sends the remainder elsewhere
         otter_set_error("otter_gemm (256x256): M=%d is not a positive multiple of %d", M, TM);
         return OTTER_ERR_UNSUPPORTED_SHAPE;
     }
-    Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, (N + TN - 1) / TN};
+    Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, (N + TN - 1) / TN, ln_stats, ln_colsum};
     return dtype == DT_BF16 ? dispatch256<__bf16>(a, act, out_f32, res, s) : dispatch256<_Float16>(a, act, out_f32, res, s);
 }

@@ -25,6 +25,8 @@ struct TailArgs {
     const void* residual; long ldr;     // in the OUTPUT's type
     void* C; long ldc;
     int M, N, K, tiles_m, tiles_n;
+    const float* ln_stats;      // [M][2] (mean, rstd) or null: LayerNorm folded into the epilogue (see otter_gemm_ln)
+    const float* ln_colsum;     // [N]
 };
 
 enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU = 2, ACT_RELU = 3 };
@@ -130,11 +132,23 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
         b0 = *(const f32x4*)(p.bias + n);
         b1 = *(const f32x4*)(p.bias + n + 4);
     }
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    if (p.ln_stats) {
+        c0 = *(const f32x4*)(p.ln_colsum + n);
+        c1 = *(const f32x4*)(p.ln_colsum + n + 4);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 32 + i * 16 + li;
         if (m >= p.M) continue;
-        f32x4 v0 = acc[i][0] + b0, v1 = acc[i][1] + b1;
+        f32x4 v0 = acc[i][0], v1 = acc[i][1];
+        if (p.ln_stats) {
+            const f32x2 st = *(const f32x2*)(p.ln_stats + 2 * (long)m);
+            v0 = (v0 - st[0] * c0) * st[1];
+            v1 = (v1 - st[0] * c1) * st[1];
+        }
+        v0 += b0;
+        v1 += b1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v0[e] = act_t<ACT>(v0[e]);
@@ -234,8 +248,9 @@ bool otter_gemm64_eligible(int dtype, long lda, int n_pad, int M, int N, int K, 
 }
 
 int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
-                        void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, hipStream_t s) {
-    TailArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB};
+                        void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
+                        const float* ln_colsum, hipStream_t s) {
+    TailArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB, ln_stats, ln_colsum};
     if (dtype == DT_F32) return dispatch_tail_f32(a, act, res, s);
     return dtype == DT_BF16 ? dispatch_tail<__bf16>(a, act, out_f32, res, s) : dispatch_tail<_Float16>(a, act, out_f32, res, s);
 }

@@ -12,6 +12,7 @@
 namespace {
 
 enum { SRC_PLAIN = 0, SRC_VIT = 1, SRC_TEXT = 2 };
+enum { DT_STATS = 3 };      // output code of otter_row_stats: y[row] = {mean, rstd}, nothing else is written
 
 struct LnArgs {
     const void* x; long ldx;             // fp32, or (SRC_PLAIN only) bf16 / fp16
@@ -82,6 +83,10 @@ __global__ __launch_bounds__(256) void ln_rows(LnArgs p) {
             }
         }
         rstd = rsqrtf(wave_sum(sq) / (float)p.width + p.eps);
+    }
+    if constexpr (OUT_DT == DT_STATS) {
+        if (lane == 0) *(f32x2*)((float*)p.y + 2 * (long)row) = (f32x2){mean, rstd};
+        return;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -188,4 +193,21 @@ extern "C" int otter_text_embed(const int* ids, int ctx, int take, const float* 
     a.x = token_embedding; a.ldx = width; a.y = x; a.ldy = ldx; a.rows = batch * take; a.width = width;
     a.pos = pos_embedding; a.ids = ids; a.ctx = ctx; a.take = take; a.vocab = vocab;
     return launch_ln_out<SRC_TEXT, DT_F32, false>(a, out_dtype, (hipStream_t)stream, "otter_text_embed");
+}
+
+extern "C" int otter_row_stats(const void* x, int in_dtype, long ldx, float* stats, int rows, int width, float eps, void* stream) {
+    OTTER_REQUIRE(x && stats, OTTER_ERR_INVALID_ARGUMENT, "otter_row_stats: null operand");
+    if (rows == 0) return OTTER_OK;
+    OTTER_REQUIRE(rows > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_row_stats: rows=%d", rows);
+    if (int rc = check_width(width, "otter_row_stats")) return rc;
+    OTTER_REQUIRE(ldx >= width && ldx % 4 == 0 && aligned16(x) && (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, OTTER_ERR_ALIGNMENT,
+                  "otter_row_stats: x must be 16-byte aligned with ldx a multiple of 4, stats 8-byte aligned");
+    LnArgs a{};
+    a.x = x; a.ldx = ldx; a.y = stats; a.ldy = 2; a.rows = rows; a.width = width; a.eps = eps;
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == DT_F32) return launch_ln<SRC_PLAIN, DT_F32, DT_STATS, true>(a, s, "otter_row_stats");
+    if (in_dtype == DT_BF16) return launch_ln<SRC_PLAIN, DT_BF16, DT_STATS, true>(a, s, "otter_row_stats");
+    if (in_dtype == DT_F16) return launch_ln<SRC_PLAIN, DT_F16, DT_STATS, true>(a, s, "otter_row_stats");
+    otter_set_error("otter_row_stats: unknown in_dtype %d", in_dtype);
+    return OTTER_ERR_INVALID_ARGUMENT;
 }

@@ -40,19 +40,26 @@ def _f32(t: Tensor, device) -> Tensor:
 class _Block:
     """One pre-LN residual attention block with packed weights (CLIP resblock or policy layer)."""
 
-    def __init__(self, device, dtype, ln1, wqkv, bqkv, wo, bo, ln2, w_fc, b_fc, w_proj, b_proj):
+    def __init__(self, device, dtype, ln1, wqkv, bqkv, wo, bo, ln2, w_fc, b_fc, w_proj, b_proj, fold_ln: bool = False):
+        """``fold_ln``: ln_1 / ln_2 are folded into in_proj / c_fc (``ops.fold_layernorm``): those two GEMMs then read the
+        residual stream directly and the normalised activations are never written."""
         self.dtype = dtype
+        self.fold_ln = fold_ln
         self.ln1 = (_f32(ln1[0], device), _f32(ln1[1], device))
         self.ln2 = (_f32(ln2[0], device), _f32(ln2[1], device))
         self.n_qkv, self.width = wqkv.shape
-        self.wqkv, self.bqkv = ops.pack_weight(wqkv.float(), dtype, device), _f32(bqkv, device)
-        self.wo, self.bo = ops.pack_weight(wo.float(), dtype, device), _f32(bo, device)
         self.n_fc = w_fc.shape[0]
-        self.w_fc, self.b_fc = ops.pack_weight(w_fc.float(), dtype, device), _f32(b_fc, device)
+        if fold_ln:
+            self.wqkv, self.bqkv, self.cs_qkv = ops.fold_layernorm(wqkv.to(device), bqkv.to(device), self.ln1[0], self.ln1[1], dtype, device)
+            self.w_fc, self.b_fc, self.cs_fc = ops.fold_layernorm(w_fc.to(device), b_fc.to(device), self.ln2[0], self.ln2[1], dtype, device)
+        else:
+            self.wqkv, self.bqkv = ops.pack_weight(wqkv.float(), dtype, device), _f32(bqkv, device)
+            self.w_fc, self.b_fc = ops.pack_weight(w_fc.float(), dtype, device), _f32(b_fc, device)
+        self.wo, self.bo = ops.pack_weight(wo.float(), dtype, device), _f32(bo, device)
         self.w_proj, self.b_proj = ops.pack_weight(w_proj.float(), dtype, device), _f32(b_proj, device)
 
 
-def _clip_blocks(sd: Dict[str, Tensor], prefix: str, device, dtype) -> List[_Block]:
+def _clip_blocks(sd: Dict[str, Tensor], prefix: str, device, dtype, fold_ln: bool = False) -> List[_Block]:
     blocks = []
     i = 0
     while f"{prefix}resblocks.{i}.ln_1.weight" in sd:
@@ -62,7 +69,7 @@ def _clip_blocks(sd: Dict[str, Tensor], prefix: str, device, dtype) -> List[_Blo
             sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"],
             sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"],
             (sd[p + "ln_2.weight"], sd[p + "ln_2.bias"]),
-            sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"]))
+            sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"], fold_ln=fold_ln))
         i += 1
     return blocks
 
@@ -89,7 +96,8 @@ class ClipDevice:
         self.vpos = _f32(sd[v + "positional_embedding"], device)
         self.ln_pre = (_f32(sd[v + "ln_pre.weight"], device), _f32(sd[v + "ln_pre.bias"], device))
         self.ln_post = (_f32(sd[v + "ln_post.weight"], device), _f32(sd[v + "ln_post.bias"], device))
-        self.vblocks = _clip_blocks(sd, v + "transformer.", device, dtype)
+        # vision tower: LayerNorm folded into the GEMMs when the residual stream has the operand type (the GEMM reads it)
+        self.vblocks = _clip_blocks(sd, v + "transformer.", device, dtype, fold_ln=self.stream_dtype == dtype)
         proj = sd[v + "proj"].float()
         self.embed = proj.shape[1]
         self.w_vproj = ops.pack_weight(proj.t().contiguous(), dtype, device)
@@ -109,15 +117,21 @@ class ClipDevice:
                     stop_after_last_attention: bool) -> Tensor:
         last = None
         for i, b in enumerate(blocks):
-            h = ops.layernorm(x, *b.ln1, out_dtype=self.dtype)
-            qkv = ops.gemm(h, b.wqkv, b.n_qkv, b.bqkv)
+            if b.fold_ln:
+                qkv = ops.gemm(x, b.wqkv, b.n_qkv, b.bqkv, ln_stats=ops.row_stats(x), ln_colsum=b.cs_qkv)
+            else:
+                h = ops.layernorm(x, *b.ln1, out_dtype=self.dtype)
+                qkv = ops.gemm(h, b.wqkv, b.n_qkv, b.bqkv)
             a = ops.attn_d64(qkv, n_seq, seq_len, heads, causal)
             if stop_after_last_attention and i == len(blocks) - 1:
                 last = ops.gemm(a, b.wo, b.width, b.bo, out_f32=True)
                 break
             ops.gemm(a, b.wo, b.width, b.bo, residual=x, out=x)
-            h = ops.layernorm(x, *b.ln2, out_dtype=self.dtype)
-            m = ops.gemm(h, b.w_fc, b.n_fc, b.b_fc, act=self.act)
+            if b.fold_ln:
+                m = ops.gemm(x, b.w_fc, b.n_fc, b.b_fc, act=self.act, ln_stats=ops.row_stats(x), ln_colsum=b.cs_fc)
+            else:
+                h = ops.layernorm(x, *b.ln2, out_dtype=self.dtype)
+                m = ops.gemm(h, b.w_fc, b.n_fc, b.b_fc, act=self.act)
             ops.gemm(m, b.w_proj, b.width, b.b_proj, residual=x, out=x)
         return last if stop_after_last_attention else x
 

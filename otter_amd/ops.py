@@ -79,6 +79,7 @@ def pack_weight(w: Tensor, dtype=torch.bfloat16, device=None) -> Tensor:
 
 def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
          out_f32: bool = False, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
+         ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None,
          force_tile_128: bool = False) -> Tensor:
     """out[M, n] = epilogue(a[M, K] @ w[n, K]^T + bias); operands bf16 / fp16 / fp32 (``w_packed`` from
     :func:`pack_weight` with the same dtype); output the operand type, or fp32 (``out_f32``, an fp32 residual, fp32
@@ -114,6 +115,17 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
             raise ValueError("gemm: residual shape mismatch")
     if m == 0:
         return out
+    if ln_stats is not None:
+        # LayerNorm folded into the epilogue: w_packed holds W * gamma, bias holds bias + W . beta (see fold_layernorm)
+        if residual is not None or ln_colsum is None:
+            raise ValueError("gemm: ln_stats goes with ln_colsum and without a residual")
+        _chk(ln_stats, torch.float32, "gemm.ln_stats", 2)
+        _chk(ln_colsum, torch.float32, "gemm.ln_colsum", 1)
+        if tuple(ln_stats.shape) != (m, 2) or ln_colsum.numel() < n or not ln_stats.is_contiguous():
+            raise ValueError("gemm: ln_stats must be (M, 2) contiguous and ln_colsum at least N long")
+        _lib.call("otter_gemm_ln", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(ln_stats), _ptr(ln_colsum),
+                  _ptr(out), ldc, m, n, k, epi, _stream())
+        return out
     _lib.call("otter_gemm", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
               _ptr(out), ldc, m, n, k, epi, _stream())
     return out
@@ -141,6 +153,29 @@ def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], *, eps
         return out
     _lib.call("otter_layernorm", _ptr(x), idt, ldx, _ptr(gamma), _ptr(beta), _ptr(out), ldy, rows, width, eps, dt, _stream())
     return out
+
+
+def row_stats(x: Tensor, eps: float = 1e-5) -> Tensor:
+    """(rows, 2) fp32: mean and 1/sqrt(var + eps) of every row of x (fp32 or 16-bit)."""
+    _chk(x, x.dtype, "row_stats.x")
+    rows, width, ldx = _rows_view(x, "row_stats.x")
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    if rows:
+        _lib.call("otter_row_stats", _ptr(x), _dt(x.dtype, "row_stats.x"), ldx, _ptr(stats), rows, width, eps, _stream())
+    return stats
+
+
+def fold_layernorm(weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, dtype, device=None):
+    """Fold ``LayerNorm(gamma, beta)`` into the Linear that follows it: (packed W * gamma in ``dtype``, bias + W . beta,
+    column sums of the ROUNDED W * gamma) -- the operands of ``gemm(..., ln_stats=row_stats(x), ln_colsum=...)``."""
+    w = weight.detach().float()
+    wg = w * gamma.detach().float()[None, :]
+    packed = pack_weight(wg, dtype, device)
+    colsum = packed.float().sum(dim=1).contiguous()                      # over the padded K too (padding is zero)
+    b = w @ beta.detach().float()
+    if bias is not None:
+        b = b + bias.detach().float()
+    return packed, b.to(packed.device).contiguous(), colsum
 
 
 def vit_embed_lnpre(patch_tok: Tensor, cls: Tensor, pos: Tensor, gamma: Tensor, beta: Tensor, n_img: int, n_patches: int,

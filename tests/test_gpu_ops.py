@@ -117,6 +117,32 @@ def test_gemm_residual_in_operand_type(dev, m, n, k, dtype):
         ops.gemm(a, wp, n, bias, residual=x.to(torch.float16 if dt == torch.bfloat16 else torch.bfloat16))
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("m,n,k,act", [(32896 // 4, 1024, 1024, "none"), (300, 256, 128, "quickgelu"), (70, 64, 64, "none")])
+def test_gemm_with_folded_layernorm(dev, m, n, k, act, dtype):
+    """LayerNorm folded into the GEMM epilogue == LayerNorm in fp32 followed by the GEMM, on all three kernels
+    (256x256 tiles + 64x64 remainder rows, 128x128, 64x64)."""
+    from otter_amd import ops
+    dt = DTYPES[dtype]
+    x = (_randn(41, m, k) * 3 + 0.7).to(dev).to(dt)                      # the residual stream: rows with a common offset
+    w = (_randn(42, n, k) / math.sqrt(k)).to(dev)
+    bias = _randn(43, n).to(dev)
+    gamma = (_randn(44, k) * 0.3 + 1).to(dev)
+    beta = (_randn(45, k) * 0.2).to(dev)
+    wp, bf, cs = ops.fold_layernorm(w, bias, gamma, beta, dt, dev)
+    stats = ops.row_stats(x)
+    xf = x.float()
+    torch.testing.assert_close(stats[:, 0], xf.mean(-1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stats[:, 1], (xf.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-5, atol=1e-5)
+    ref = torch.nn.functional.layer_norm(xf, (k,), gamma, beta, 1e-5) @ w.t() + bias
+    if act == "quickgelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    for kw in ({}, dict(force_tile_128=True)):
+        out = ops.gemm(x, wp, n, bf, act=ACTS[act], ln_stats=stats, ln_colsum=cs, **kw)
+        tol = 3e-2 if dtype == "bf16" else 4e-3                          # rounding of W * gamma and of the output
+        torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)
+
+
 @pytest.mark.parametrize("m", [777, 1300])          # 128-row tiles only / 256-row tiles plus a 128-row-tile remainder
 def test_gemm_residual_strided_inplace(dev, m):
     from otter_amd import ops

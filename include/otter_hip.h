@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 7
+#define OTTER_HIP_ABI_VERSION 8
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -60,6 +60,15 @@ int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, con
  * (mean, rstd) from otter_row_stats; the other arguments as otter_gemm (no residual epilogue). */
 int otter_gemm_ln(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const float* row_stats,
                   const float* col_sum, void* C, long ldc, int M, int N, int K, int epilogue, void* stream);
+/* otter_gemm / otter_gemm_ln with a caller-provided scratch buffer (row_stats / col_sum NULL = no folded LayerNorm).
+ * With it the < 256 remainder rows of a big 16-bit problem (the CLIP towers have 32896 = 128 x 257 token rows) are
+ * multiplied split-K over the whole chip: fp32 partial products go to `workspace`, a second launch sums them and applies
+ * the epilogue.  workspace: >= otter_gemm_workspace_floats(N) floats, 16-byte aligned, private to the stream for the
+ * duration of the call; NULL = as otter_gemm.  Results are deterministic (fixed summation order). */
+long otter_gemm_workspace_floats(int N);
+int otter_gemm_ws(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const void* residual,
+                  long ldr, const float* row_stats, const float* col_sum, void* C, long ldc, int M, int N, int K, int epilogue,
+                  float* workspace, long workspace_floats, void* stream);
 /* stats[r] = (mean, 1/sqrt(var + eps)) of row r (two-pass, fp32), x fp32 or 16-bit. */
 int otter_row_stats(const void* x, int in_dtype, long ldx, float* stats, int rows, int width, float eps, void* stream);
 

@@ -32,6 +32,10 @@ int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const
                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
                         const float* ln_colsum, hipStream_t s);
 
+int otter_gemm64_splitk_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
+                               void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
+                               const float* ln_colsum, float* workspace, int splits, hipStream_t s);
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -234,9 +238,19 @@ int dispatch(const GemmArgs& a, int act, bool out_f32, bool res, hipStream_t s) 
 
 }  // namespace
 
+// Split-K factor for a 16-bit problem on the 64x64 kernel: few tiles (each would pull its whole K panel through one CU)
+// and a K loop long enough to cut; 1 = do not split.  About two workgroups per CU at most.
+static int pick_splits(int dtype, int M, int N, int K, const float* workspace, long workspace_floats) {
+    if (!workspace || dtype == DT_F32 || N % 8 != 0) return 1;
+    const int nk = K / 64, tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    for (int sp = 8; sp > 1; sp >>= 1)
+        if (nk % sp == 0 && nk / sp >= 2 && tiles * sp <= 512 && (long)sp * M * N <= workspace_floats) return sp;
+    return 1;
+}
+
 static int gemm_impl(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias,
                      const void* residual, long ldr, void* C, long ldc, int M, int N, int K,
-                     int epilogue, const float* ln_stats, const float* ln_colsum, void* stream) {
+                     int epilogue, const float* ln_stats, const float* ln_colsum, float* workspace, long workspace_floats, void* stream) {
     OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16 || dtype == DT_F32, OTTER_ERR_INVALID_ARGUMENT, "otter_gemm: unknown dtype %d", dtype);
     const int es = dtype == DT_F32 ? 4 : 2;
     const int kq = ROW_BYTES / es;
@@ -269,13 +283,25 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, int n_pa
         int rc = otter_gemm256_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, m_main, N, K, act, out_f32, res, ln_stats, ln_colsum, s);
         if (rc != OTTER_OK || m_main == M) return rc;
         const long ec = (out_f32 ? 4 : es);
+        const int rem = M - m_main;
+        const int splits = pick_splits(dtype, rem, N, K, workspace, workspace_floats);
+        if (splits > 1)
+            return otter_gemm64_splitk_launch(dtype, (const char*)A + (long)m_main * lda * es, lda, W, bias,
+                                              res ? (const char*)residual + (long)m_main * ldr * ec : nullptr, ldr,
+                                              (char*)C + (long)m_main * ldc * ec, ldc, rem, N, K, act, out_f32, res,
+                                              ln_stats ? ln_stats + 2 * (long)m_main : nullptr, ln_colsum, workspace, splits, s);
         return otter_gemm64_launch(dtype, (const char*)A + (long)m_main * lda * es, lda, W, bias,
                                       res ? (const char*)residual + (long)m_main * ldr * ec : nullptr, ldr, (char*)C + (long)m_main * ldc * ec, ldc,
                                       M - m_main, N, K, act, out_f32, res, ln_stats ? ln_stats + 2 * (long)m_main : nullptr, ln_colsum, s);
     }
     // too few 128x128 tiles to give every CU one: the 64x64 kernel spreads the problem over 4x more workgroups
-    if (!(epilogue & OTTER_EPI_TILE_128) && (long)tiles_m * tiles_n < 256 && otter_gemm64_eligible(dtype, lda, n_pad, M, N, K, C, ldc))
+    if (!(epilogue & OTTER_EPI_TILE_128) && (long)tiles_m * tiles_n < 256 && otter_gemm64_eligible(dtype, lda, n_pad, M, N, K, C, ldc)) {
+        const int splits = pick_splits(dtype, M, N, K, workspace, workspace_floats);
+        if (splits > 1)
+            return otter_gemm64_splitk_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, M, N, K, act, out_f32, res, ln_stats, ln_colsum,
+                                              workspace, splits, s);
         return otter_gemm64_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, M, N, K, act, out_f32, res, ln_stats, ln_colsum, s);
+    }
     const int tm = (M + BM - 1) / BM;
     GemmArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, tm, tiles_n, ln_stats, ln_colsum};
     if (dtype == DT_BF16) return dispatch<__bf16>(a, act, out_f32, res, s);
@@ -286,7 +312,7 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, int n_pa
 extern "C" int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias,
                           const void* residual, long ldr, void* C, long ldc, int M, int N, int K,
                           int epilogue, void* stream) {
-    return gemm_impl(dtype, A, lda, W, n_pad, bias, residual, ldr, C, ldc, M, N, K, epilogue, nullptr, nullptr, stream);
+    return gemm_impl(dtype, A, lda, W, n_pad, bias, residual, ldr, C, ldc, M, N, K, epilogue, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int otter_gemm_ln(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias,
@@ -295,5 +321,16 @@ extern "C" int otter_gemm_ln(int dtype, const void* A, long lda, const void* W, 
     OTTER_REQUIRE(row_stats && col_sum && aligned16(col_sum) && (reinterpret_cast<uintptr_t>(row_stats) & 7u) == 0, OTTER_ERR_INVALID_ARGUMENT,
                   "otter_gemm_ln: row_stats (8-byte aligned) and col_sum (16-byte aligned) are required");
     OTTER_REQUIRE(!(epilogue & OTTER_EPI_RESIDUAL), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_ln: no residual epilogue");
-    return gemm_impl(dtype, A, lda, W, n_pad, bias, nullptr, 0, C, ldc, M, N, K, epilogue, row_stats, col_sum, stream);
+    return gemm_impl(dtype, A, lda, W, n_pad, bias, nullptr, 0, C, ldc, M, N, K, epilogue, row_stats, col_sum, nullptr, 0, stream);
+}
+
+extern "C" long otter_gemm_workspace_floats(int N) { return 8L * 255 * N; }
+
+extern "C" int otter_gemm_ws(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const void* residual,
+                             long ldr, const float* row_stats, const float* col_sum, void* C, long ldc, int M, int N, int K,
+                             int epilogue, float* workspace, long workspace_floats, void* stream) {
+    OTTER_REQUIRE((row_stats == nullptr) == (col_sum == nullptr), OTTER_ERR_INVALID_ARGUMENT, "otter_gemm_ws: row_stats and col_sum go together");
+    OTTER_REQUIRE(!row_stats || !(epilogue & OTTER_EPI_RESIDUAL), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_ws: folded LayerNorm takes no residual");
+    OTTER_REQUIRE(!workspace || (aligned16(workspace) && workspace_floats > 0), OTTER_ERR_ALIGNMENT, "otter_gemm_ws: workspace must be 16-byte aligned");
+    return gemm_impl(dtype, A, lda, W, n_pad, bias, residual, ldr, C, ldc, M, N, K, epilogue, row_stats, col_sum, workspace, workspace_floats, stream);
 }

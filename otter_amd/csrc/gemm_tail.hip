@@ -27,6 +27,8 @@ struct TailArgs {
     int M, N, K, tiles_m, tiles_n;
     const float* ln_stats;      // [M][2] (mean, rstd) or null: LayerNorm folded into the epilogue (see otter_gemm_ln)
     const float* ln_colsum;     // [N]
+    int k_splits;
+    float* partial;             // split-K: [gridDim.y][M][N] fp32 partial products (the epilogue runs in splitk_reduce), or null
 };
 
 enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU = 2, ACT_RELU = 3 };
@@ -96,16 +98,18 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K * ES / ROWB;
+    // split-K: workgroup (x, y) multiplies K-steps [y*nk, (y+1)*nk) of the tile
+    const int nk = p.K * ES / ROWB / (int)gridDim.y;
+    const unsigned kbase = blockIdx.y * (unsigned)nk * ROWB;
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
-        if (t < nk) stage(t, (unsigned)t * ROWB);
+        if (t < nk) stage(t, kbase + (unsigned)t * ROWB);
     for (int t = 0; t < nk; ++t) {
         // stages t .. t+NS-2 have been issued (4 instructions each per thread): retire stage t only
         if (t + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");           // stage t visible to all waves; everyone is done with stage t-1
-        if (t + NS - 1 < nk) stage((t + NS - 1) % NS, (unsigned)(t + NS - 1) * ROWB);
+        if (t + NS - 1 < nk) stage((t + NS - 1) % NS, kbase + (unsigned)(t + NS - 1) * ROWB);
         const int cur = t % NS;
         const char* sA = smem + cur * STAGE + wm * 32 * ROWB;
         const char* sW = smem + cur * STAGE + TB * ROWB + wn * 32 * ROWB;
@@ -127,6 +131,17 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
     // epilogue: lane holds row m = li (per m-tile) and columns 8g + 0..7 of the wave's 32
     const int n = n0 + wn * 32 + g * 8;
     if (n >= p.N) return;
+    if (p.partial) {
+        float* part = p.partial + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 32 + i * 16 + li;
+            if (m >= p.M) continue;
+            *(f32x4*)(part + (long)m * p.N + n) = acc[i][0];
+            *(f32x4*)(part + (long)m * p.N + n + 4) = acc[i][1];
+        }
+        return;
+    }
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
         b0 = *(const f32x4*)(p.bias + n);
@@ -196,7 +211,7 @@ int launch_tail_ns(const TailArgs& a, hipStream_t s) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), NS * STAGE, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, a.partial ? a.k_splits : 1), dim3(256), NS * STAGE, s, a);
     OTTER_CHECK_LAUNCH("otter_gemm (64x64)");
     return OTTER_OK;
 }
@@ -236,7 +251,78 @@ int dispatch_tail(const TailArgs& a, int act, bool out_f32, bool res, hipStream_
     return OTTER_ERR_INVALID_ARGUMENT;
 }
 
+// Second pass of a split-K product: sums the partial products and applies the epilogue of the one-pass kernels
+// (folded LayerNorm, bias, activation, residual in the output's type).  One thread per 4 consecutive columns.
+struct ReduceArgs {
+    const float* partial; int splits;
+    const float* bias; const void* residual; long ldr;
+    void* C; long ldc;
+    int M, N, act, out_dt, res;
+    const float* ln_stats; const float* ln_colsum;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce(ReduceArgs p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = p.N >> 2;
+    if (i >= (long)p.M * nq) return;
+    const int m = (int)(i / nq), n = (int)(i % nq) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.splits; ++s) v += *(const f32x4*)(p.partial + ((long)s * p.M + m) * p.N + n);
+    if (p.ln_stats) {
+        const f32x2 st = *(const f32x2*)(p.ln_stats + 2 * (long)m);
+        v = (v - st[0] * *(const f32x4*)(p.ln_colsum + n)) * st[1];
+    }
+    if (p.bias) v += *(const f32x4*)(p.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (p.act == ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
+        else if (p.act == ACT_GELU) v[e] = gelu_erf(v[e]);
+        else if (p.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (p.out_dt == DT_F32) {
+        if (p.res) v += *(const f32x4*)((const float*)p.residual + (long)m * p.ldr + n);
+        *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
+    } else if (p.out_dt == DT_F16) {
+        if (p.res) {
+            const f16x4 r = *(const f16x4*)((const _Float16*)p.residual + (long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+        }
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = Half16<_Float16>::from(v[e]);
+        *(f16x4*)((_Float16*)p.C + (long)m * p.ldc + n) = o;
+    } else {
+        if (p.res) {
+            const bf16x4 r = *(const bf16x4*)((const __bf16*)p.residual + (long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = Half16<__bf16>::from(v[e]);
+        *(bf16x4*)((__bf16*)p.C + (long)m * p.ldc + n) = o;
+    }
+}
+
 }  // namespace
+
+// Split-K for problems with too few 64x64 tiles to occupy the chip (the < 256 remainder rows of the tower GEMMs: 32
+// tiles, each pulling 1 MB through one CU): `splits` workgroups per tile write fp32 partial products to `workspace`
+// ([splits][M][N] floats, caller-provided), a second launch sums them and applies the epilogue.  16-bit operands only.
+int otter_gemm64_splitk_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
+                               void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
+                               const float* ln_colsum, float* workspace, int splits, hipStream_t s) {
+    TailArgs a{(const char*)A, lda, (const char*)W, nullptr, nullptr, 0, nullptr, 0, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB,
+               nullptr, nullptr, splits, workspace};
+    int rc = dtype == DT_BF16 ? launch_tail_ns<__bf16, ACT_NONE, true, false, 4>(a, s) : launch_tail_ns<_Float16, ACT_NONE, true, false, 4>(a, s);
+    if (rc != OTTER_OK) return rc;
+    ReduceArgs r{workspace, splits, bias, residual, ldr, C, ldc, M, N, act, out_f32 ? DT_F32 : dtype, res ? 1 : 0, ln_stats, ln_colsum};
+    const long threads = (long)M * (N / 4);
+    hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, r);
+    OTTER_CHECK_LAUNCH("otter_gemm (split-K reduce)");
+    return OTTER_OK;
+}
 
 // Shapes the 64x64 kernel accepts: 8-column vector stores and 32-bit source offsets.
 bool otter_gemm64_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc) {
@@ -250,7 +336,7 @@ bool otter_gemm64_eligible(int dtype, long lda, int n_pad, int M, int N, int K, 
 int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
                         const float* ln_colsum, hipStream_t s) {
-    TailArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB, ln_stats, ln_colsum};
+    TailArgs a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB, ln_stats, ln_colsum, 1, nullptr};
     if (dtype == DT_F32) return dispatch_tail_f32(a, act, res, s);
     return dtype == DT_BF16 ? dispatch_tail<__bf16>(a, act, out_f32, res, s) : dispatch_tail<_Float16>(a, act, out_f32, res, s);
 }

@@ -77,13 +77,27 @@ def pack_weight(w: Tensor, dtype=torch.bfloat16, device=None) -> Tensor:
 
 # ----------------------------------------------------------------------------------------- kernels
 
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device, n: int) -> Tensor:
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    need = _lib.load().otter_gemm_workspace_floats(round_up(n, 64))
+    ws = _GEMM_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _GEMM_WS[key] = torch.empty(need, dtype=torch.float32, device=device)
+    return ws
+
+
 def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
          out_f32: bool = False, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
          ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None,
-         force_tile_128: bool = False) -> Tensor:
+         force_tile_128: bool = False, split_k: bool = True) -> Tensor:
     """out[M, n] = epilogue(a[M, K] @ w[n, K]^T + bias); operands bf16 / fp16 / fp32 (``w_packed`` from
     :func:`pack_weight` with the same dtype); output the operand type, or fp32 (``out_f32``, an fp32 residual, fp32
-    operands).  ``residual`` (fp32, or the operands' 16-bit type) is added after the bias and fixes the output type."""
+    operands).  ``residual`` (fp32, or the operands' 16-bit type) is added after the bias and fixes the output type.
+    ``split_k``: few-tile 16-bit problems and the < 256 remainder rows of big ones may be multiplied split-K through a
+    scratch buffer (deterministic; rows can differ from the one-pass kernels in the last bit of the fp32 sum)."""
     dt = _dt(a.dtype, "gemm.a")
     _chk(a, a.dtype, "gemm.a")
     _chk(w_packed, a.dtype, "gemm.w", 2)
@@ -123,11 +137,10 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         _chk(ln_colsum, torch.float32, "gemm.ln_colsum", 1)
         if tuple(ln_stats.shape) != (m, 2) or ln_colsum.numel() < n or not ln_stats.is_contiguous():
             raise ValueError("gemm: ln_stats must be (M, 2) contiguous and ln_colsum at least N long")
-        _lib.call("otter_gemm_ln", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(ln_stats), _ptr(ln_colsum),
-                  _ptr(out), ldc, m, n, k, epi, _stream())
-        return out
-    _lib.call("otter_gemm", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
-              _ptr(out), ldc, m, n, k, epi, _stream())
+    # scratch for the split-K pass over the remainder rows of a big 16-bit problem (one buffer per device and stream)
+    ws = _gemm_workspace(a.device, n) if (split_k and a.dtype != torch.float32 and (m % 256 != 0 or m < 1024)) else None
+    _lib.call("otter_gemm_ws", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
+              _ptr(ln_stats), _ptr(ln_colsum), _ptr(out), ldc, m, n, k, epi, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     return out
 
 

@@ -90,9 +90,9 @@ def test_gemm_128_tile_kernel(dev, m, n, k, dtype):
     wp = ops.pack_weight(w, dt)
     res = _randn(14, m, n).to(dev)
     for kw in (dict(act=ACTS["gelu"]), dict(residual=res)):
-        ref = ops.gemm(a, wp, n, bias, **kw)
+        ref = ops.gemm(a, wp, n, bias, split_k=False, **kw)
         out = ops.gemm(a, wp, n, bias, force_tile_128=True, **kw)
-        assert torch.equal(out, ref)              # same products, same fp32 accumulation order along K
+        assert torch.equal(out, ref)              # same products, same fp32 accumulation order along K (one-pass kernels)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -141,6 +141,33 @@ def test_gemm_with_folded_layernorm(dev, m, n, k, act, dtype):
         out = ops.gemm(x, wp, n, bf, act=ACTS[act], ln_stats=stats, ln_colsum=cs, **kw)
         tol = 3e-2 if dtype == "bf16" else 4e-3                          # rounding of W * gamma and of the output
         torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("m,n,k", [(128, 1024, 4096), (32896 // 2, 1024, 1024), (100, 3072, 1024), (70, 64, 512)])
+def test_gemm_split_k_matches_one_pass(dev, m, n, k, dtype):
+    """Few-tile 16-bit problems (and the remainder rows of big ones) are multiplied split-K through a scratch buffer:
+    same epilogues, results equal to the one-pass kernel up to the fp32 summation order."""
+    from otter_amd import ops, _lib
+    dt = DTYPES[dtype]
+    a = (_randn(51, m, k) * 0.5).to(dev).to(dt)
+    w = (_randn(52, n, k) / math.sqrt(k)).to(dev)
+    bias = _randn(53, n).to(dev)
+    wp = ops.pack_weight(w, dt)
+    x = _randn(54, m, n).to(dev).to(dt)
+    lib = _lib.load()
+    def one_pass(act, residual):
+        out = torch.empty(m, n, dtype=dt, device=dev)
+        epi = act | (8 if residual is not None else 0)
+        _lib.call("otter_gemm", ops._dt(dt, "t"), ops._ptr(a), k, ops._ptr(wp), wp.shape[0], ops._ptr(bias), ops._ptr(residual), n,
+                  ops._ptr(out), n, m, n, k, epi, ops._stream())
+        return out
+    for act, residual in ((ACTS["none"], None), (ACTS["quickgelu"], None), (ACTS["none"], x)):
+        got = ops.gemm(a, wp, n, bias, act=act, residual=residual)          # the wrapper passes the scratch buffer
+        ref = one_pass(act, residual)
+        tol = 2e-2 if dtype == "bf16" else 2e-3                           # one 16-bit rounding apart at most
+        torch.testing.assert_close(got.float(), ref.float(), rtol=tol, atol=tol)
+    assert lib.otter_gemm_workspace_floats(n) >= 8 * 255 * n
 
 
 @pytest.mark.parametrize("m", [777, 1300])          # 128-row tiles only / 256-row tiles plus a 128-row-tile remainder

@@ -7,6 +7,7 @@ passes raw pointers to ``libotter_hip.so``.  No function here computes anything 
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -78,6 +79,7 @@ def pack_weight(w: Tensor, dtype=torch.bfloat16, device=None) -> Tensor:
 # ----------------------------------------------------------------------------------------- kernels
 
 _GEMM_WS = {}
+_SPLIT_K = os.environ.get("OTTER_SPLIT_K", "1") != "0"       # tuning knob: 0 = never take the split-K path
 
 
 def _gemm_workspace(device, n: int) -> Tensor:
@@ -138,7 +140,7 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         if tuple(ln_stats.shape) != (m, 2) or ln_colsum.numel() < n or not ln_stats.is_contiguous():
             raise ValueError("gemm: ln_stats must be (M, 2) contiguous and ln_colsum at least N long")
     # scratch for the split-K pass over the remainder rows of a big 16-bit problem (one buffer per device and stream)
-    ws = _gemm_workspace(a.device, n) if (split_k and a.dtype != torch.float32 and (m % 256 != 0 or m < 1024)) else None
+    ws = _gemm_workspace(a.device, n) if (split_k and _SPLIT_K and a.dtype != torch.float32 and (m % 256 != 0 or m < 1024)) else None
     _lib.call("otter_gemm_ws", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
               _ptr(ln_stats), _ptr(ln_colsum), _ptr(out), ldc, m, n, k, epi, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     return out

@@ -102,7 +102,7 @@ int otter_im2col_patches(int out_dtype, const void* images, int is_u8, void* out
 
 /* Multi-head self-attention with head_dim 64 over packed q|k|v rows (row = seq*L + t, width 3*heads*64);
  * dtype bf16 or fp16 (qkv and out).
- * L <= 288.  causal != 0 applies the text tower's mask.  Replaces nn.MultiheadAttention inside the CLIP
+ * L <= 592 (K and V of one head stay in LDS).  causal != 0 applies the text tower's mask.  Replaces nn.MultiheadAttention inside the CLIP
  * resblocks, including the hooked last vision block (otter.py:141-143). */
 int otter_attn_fwd_d64(int dtype, const void* qkv, long ld, void* out, long ldo, int n_seq, int L, int heads, int causal, void* stream);
 

@@ -269,7 +269,8 @@ static int dispatch_d64(const AttnArgs& a, int n_seq, int L, hipStream_t s) {
     if (L == 257 && !a.causal) return launch_d64<T, 17, 257, 4>(a, n_seq, s);    // 4 waves measured faster than 5 or 6 (79 vs 88 / 82 us per layer)      // ViT-L/14 and ViT-B/... at 224: 256 patches + CLS
     if (L <= 32) return launch_d64<T, 2, 0>(a, n_seq, s);
     if (L <= 96) return launch_d64<T, 6, 0>(a, n_seq, s);
-    return launch_d64<T, 18, 0>(a, n_seq, s);
+    if (L <= 288) return launch_d64<T, 18, 0>(a, n_seq, s);
+    return launch_d64<T, 37, 0>(a, n_seq, s);      // ViT-L/14@336px: 577 tokens, K and V fill 148 of the 160 KiB: one workgroup per CU
 }
 
 extern "C" int otter_attn_fwd_d64(int dtype, const void* qkv, long ld, void* out, long ldo, int n_seq, int L, int heads,
@@ -278,7 +279,7 @@ extern "C" int otter_attn_fwd_d64(int dtype, const void* qkv, long ld, void* out
     OTTER_REQUIRE(qkv && out, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_fwd_d64: null operand");
     if (n_seq == 0) return OTTER_OK;
     OTTER_REQUIRE(n_seq > 0 && L > 0 && heads > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_fwd_d64: n_seq=%d L=%d heads=%d", n_seq, L, heads);
-    OTTER_REQUIRE(L <= 288, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_attn_fwd_d64: L=%d exceeds 288 keys", L);
+    OTTER_REQUIRE(L <= 592, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_attn_fwd_d64: L=%d exceeds 592 keys", L);
     OTTER_REQUIRE(ld >= 3 * heads * 64 && ld % 8 == 0 && ldo >= heads * 64 && ldo % 4 == 0, OTTER_ERR_ALIGNMENT,
                   "otter_attn_fwd_d64: ld=%ld / ldo=%ld too small or misaligned for %d heads", ld, ldo, heads);
     OTTER_REQUIRE(aligned16(qkv) && aligned16(out), OTTER_ERR_ALIGNMENT, "otter_attn_fwd_d64: operands must be 16-byte aligned");

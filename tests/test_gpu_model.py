@@ -122,6 +122,32 @@ def test_default_config_vit_l14_matches_oracle(dev):
     assert worst <= 1e-3
 
 
+@pytest.mark.parametrize("clip_model,res", [("ViT-B/16", 224), ("ViT-B/32", 224), ("ViT-L/14@336px", 336)])
+def test_other_clip_backbones_match_oracle(dev, clip_model, res):
+    """The other CLIP ViTs the reference's config accepts: 196 / 49 / 576 patches (the first two are not whole 16-patch
+    tiles for the pooling kernel), 197 / 50 / 577 tokens per sequence, embedding widths 512 / 768.  Visual / text tokens
+    and one rollout step vs the oracle."""
+    from otter_amd.config import ModelConfig, SharedConfig
+    mc, sc = ModelConfig(clip_model=clip_model), SharedConfig(image_size=res)
+    model, sd = _model(mc, sc, 3, dev)
+    rng = np.random.default_rng(11)
+    images = torch.from_numpy(rng.integers(0, 256, (1, 2, 3, res, res), dtype=np.uint8))
+    text = torch.zeros(77, dtype=torch.int32)
+    text[0], text[1:5], text[5] = 49406, torch.from_numpy(rng.integers(1, 49406, 4).astype(np.int32)), 49407
+    proprio = torch.from_numpy(rng.standard_normal((1, 10)).astype(np.float32))
+    pf, tf = model.extract_clip_features(images[:1, None].to(dev), text[None])
+    with torch.no_grad():
+        ref_pf = clip_ref.patch_features(R.clip_transform(images[0]), sd)
+        ref_tf = clip_ref.text_features(text[None], 15, sd)
+    cos_patch = min(_cos(pf[c][0].cpu(), ref_pf[c]) for c in range(2))
+    cos_text = _cos(tf[0].cpu(), ref_tf[0])
+    ref = R.Rollout(sd, R.Dims()).step(R.clip_transform(images[0]), text, proprio[0]).numpy()
+    got = model.forward_inference(images[0].to(dev), text, proprio[0].to(dev)).cpu().numpy()
+    err = float(np.abs(got - ref).max())
+    print(f"{clip_model}: {pf[0].shape[1]} patches, patch cosine {cos_patch:.6f}, text cosine {cos_text:.6f}, max |action - oracle| = {err:.2e}")
+    assert cos_patch >= 0.9999 and cos_text >= 0.9999 and err <= 1e-3
+
+
 def test_batched_rollout_equals_single_episode(dev):
     """B concurrent episodes give each episode what it gets alone; a per-episode reset does not disturb the others."""
     from otter_amd.engine import BatchedRollout

@@ -273,7 +273,7 @@ def _sdpa_ref(qkv, n_seq, L, heads, hd, causal):
 
 
 @pytest.mark.parametrize("n_seq,L,heads,causal", [(3, 257, 16, False), (2, 15, 12, True), (2, 77, 12, True), (5, 17, 2, False),
-                                                  (1, 1, 1, True), (2, 65, 2, False), (1, 288, 1, False), (2, 16, 3, True),
+                                                  (1, 1, 1, True), (2, 65, 2, False), (1, 288, 1, False), (2, 577, 2, False), (1, 592, 1, True), (2, 16, 3, True),
                                                   (2, 40, 2, True), (1, 197, 12, False)])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_attn_d64(dev, n_seq, L, heads, causal, dtype):
@@ -434,7 +434,7 @@ def test_empty_and_limit_cases(dev):
     ops.layernorm(torch.zeros(0, 64, device=dev), torch.ones(64, device=dev), torch.zeros(64, device=dev), out_dtype=f16)
     assert ops.attn_d64(torch.zeros(0, 3 * 64, dtype=f16, device=dev), 0, 7, 1, False).shape[0] == 0
     with pytest.raises(ops.OtterHipError):
-        ops.attn_d64(torch.zeros(289, 3 * 64, dtype=f16, device=dev), 1, 289, 1, False)          # more than 288 keys
+        ops.attn_d64(torch.zeros(593, 3 * 64, dtype=f16, device=dev), 1, 593, 1, False)          # more than 592 keys
     kv = torch.zeros(1, 65, 3 * 64, device=dev)
     with pytest.raises(ops.OtterHipError):
         ops.attn_policy(kv, 1, 0, 1)                                                              # window > 64

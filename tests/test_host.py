@@ -318,6 +318,45 @@ def test_checkpoint_round_trip_in_reference_layout(tmp_path):
         assert n1 == n2 and torch.equal(p1, p2)
 
 
+def test_published_clip_weights_load_into_the_model(tmp_path):
+    """A tensors-only state_dict file in the OpenAI key layout (fp16 tensors plus the archive's three scalar entries) fills
+    clip_model.*; a wrong shape or a missing tensor is an error, and a file that is not plain tensors is refused."""
+    from otter_amd.clip_weights import load_clip_weights
+    from otter_amd.config import ModelConfig, SharedConfig
+    from otter_amd.otter import OTTER
+    mc = ModelConfig(clip_model="tiny-test", transformer_dim=128, transformer_layers=2, transformer_heads=2, vision_pooling_output_dim=128,
+                     text_pooling_output_dim=64, proprio_hidden_dim=64, proprio_output_dim=32, pooling_heads=4)
+    sc = SharedConfig(image_size=112, seq_length=4, action_horizon=4)
+    donor, model = OTTER(mc, sc), OTTER(mc, sc)
+    g = torch.Generator().manual_seed(3)
+    published = {}
+    for k, v in donor.state_dict().items():
+        if k.startswith("clip_model."):
+            published[k[len("clip_model."):]] = (torch.randn(v.shape, generator=g) * 0.05).half()
+    published.update(input_resolution=torch.tensor(112), context_length=torch.tensor(77), vocab_size=torch.tensor(49408))
+    path = str(tmp_path / "clip.pt")
+    torch.save({"state_dict": published}, path)
+    before = {k: v.clone() for k, v in model.state_dict().items() if not k.startswith("clip_model.")}
+    unused = load_clip_weights(model, path)
+    assert sorted(unused) == ["context_length", "input_resolution", "vocab_size"]
+    sd = model.state_dict()
+    for k, v in published.items():
+        if k not in unused:
+            assert torch.equal(sd["clip_model." + k], v.float()), k
+    for k, v in before.items():
+        assert torch.equal(sd[k], v), k                                   # nothing outside clip_model moved
+    bad = dict(published)
+    bad["visual.proj"] = bad["visual.proj"][:, :-1]
+    with pytest.raises(ValueError):
+        load_clip_weights(model, bad)
+    del published["ln_final.weight"]
+    with pytest.raises(KeyError):
+        load_clip_weights(model, published)
+    torch.save({"state_dict": {"visual.proj": object()}}, path)          # not tensors only: weights_only refuses it
+    with pytest.raises(Exception):
+        load_clip_weights(model, path)
+
+
 @pytest.mark.parametrize("h,w,size", [(180, 320, 224), (720, 1280, 224), (300, 200, 224), (224, 224, 224), (512, 512, 112)])
 def test_resize_arithmetic_is_pil_bicubic_bit_for_bit(h, w, size):
     """The fixed-point tables and two-pass arithmetic the GPU resize kernel uses, against PIL itself (down-scaling with

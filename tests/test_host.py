@@ -41,8 +41,8 @@ def test_abi_argument_validation_without_gpu():
     assert rc == 2 and b"multiple of 64" in lib.otter_last_error()
     rc = lib.otter_gemm(7, p, 64, p, 128, None, None, 0, p, 128, 4, 128, 64, 0, None)      # unknown dtype
     assert rc == 1
-    rc = lib.otter_attn_fwd_d64(0, p, 192, p, 64, 1, 300, 1, 0, None)                      # L too long
-    assert rc == 2 and b"288" in lib.otter_last_error()
+    rc = lib.otter_attn_fwd_d64(0, p, 192, p, 64, 1, 600, 1, 0, None)                      # L too long
+    assert rc == 2 and b"592" in lib.otter_last_error()
 
 
 def test_ops_refuse_cpu_tensors():

@@ -176,6 +176,31 @@ def measure_kernels(work, steps: int):
     return out
 
 
+def pool_saturated(device, dtype, units: int = 2048, reps: int = 10):
+    """The pooling kernel alone on enough (observation, camera) units to occupy every CU (the step's own launch has
+    128 units: one per workgroup, half the CUs idle): compulsory bytes / launch time, HIP events on the launch stream."""
+    from otter_amd import ops
+    p, d, kq, cams = 256, 768, 15, 2
+    g = torch.Generator(device=device).manual_seed(5)
+    patches = torch.randn(units, p, d, generator=g, device=device).to(dtype)
+    text = torch.randn(units // cams, kq, d, generator=g, device=device)
+    pos = torch.randn(cams, p, d, generator=g, device=device)
+    packed = torch.stack([ops.pos_emb_pack(pos[c].contiguous(), dtype) for c in range(cams)])
+    temp = torch.full((cams,), 0.07, device=device)
+    for _ in range(2):
+        ops.text_aware_pool(patches, text, packed, temp, units // cams, cams, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.text_aware_pool(patches, text, packed, temp, units // cams, cams, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    nbytes = units * (p * d * 2 + kq * d * 4 + kq * d * 4)
+    gbs = nbytes / (us * 1e-6) / 1e9
+    return {"units": units, "avg_launch_us": us, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS}
+
+
 def cpu_baseline(work: Workload, budget_s: float = 15.0):
     """fp32 CPU oracle (a port of the reference's path, validated against its fixtures) on this host's cores."""
     from oracle import otter_ref as R
@@ -272,7 +297,10 @@ def main():
             gbs = tv["total_work"] / max(tv["total_ms"] * 1e-3, 1e-12) / 1e9
             result["roofline_pool"] = {"bound": "hbm", "kernel": "tave_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                        "frac": gbs / PEAK_HBM_GBS, "traffic": None, "launches": tv["launches"],
-                                       "avg_launch_us": 1e3 * tv["total_ms"] / tv["launches"]}
+                                       "avg_launch_us": 1e3 * tv["total_ms"] / tv["launches"],
+                                       "units_per_launch": 2 * work.n}
+            if world == 1 and args.workload == "infer":
+                result["roofline_pool"]["saturated"] = pool_saturated(device, clip_dtype)
         if world == 1 and not args.no_cpu_baseline and args.workload == "infer":
             result["cpu_baseline"] = cpu_baseline(work)
         print(json.dumps(result))

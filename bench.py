@@ -201,6 +201,27 @@ def pool_saturated(device, dtype, units: int = 2048, reps: int = 10):
     return {"units": units, "avg_launch_us": us, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS}
 
 
+def library_gemm_rate(device, dtype, m: int = 32768, reps: int = 10):
+    """Measuring stick, not part of the path: the vendor library's plain products (torch.mm = hipBLASLt; no bias, activation
+    or residual) on the four GEMM shapes of one CLIP block, weighted as the block runs them.  TFLOP/s."""
+    flops = ms = 0.0
+    for n, k in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)):
+        a = torch.randn(m, k, device=device).to(dtype)
+        w = (torch.randn(n, k, device=device) / k ** 0.5).to(dtype)
+        out = torch.empty(m, n, device=device, dtype=dtype)
+        for _ in range(3):
+            torch.mm(a, w.t(), out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            torch.mm(a, w.t(), out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms += e0.elapsed_time(e1) / reps
+        flops += 2.0 * m * n * k
+    return flops / (ms * 1e-3) / 1e12
+
+
 def cpu_baseline(work: Workload, budget_s: float = 15.0):
     """fp32 CPU oracle (a port of the reference's path, validated against its fixtures) on this host's cores."""
     from oracle import otter_ref as R
@@ -293,6 +314,10 @@ def main():
                                   "algorithmic_bytes_per_launch": gm["total_bytes"] / gm["launches"], "pmc_mfma_busy_frac": mfma_busy,
                                   "launches": gm["launches"], "avg_launch_us": 1e3 * gm["total_ms"] / gm["launches"],
                                   "gemm_ms_per_step": gm["total_ms"] / 2}
+            if world == 1 and args.workload == "infer":
+                lib_tf = library_gemm_rate(device, clip_dtype)
+                result["roofline"]["vendor_library_plain_product"] = {"tflops": lib_tf, "frac_of_peak": lib_tf / PEAK_BF16_TFLOPS,
+                                                                       "note": "torch.mm (hipBLASLt) on the block's four shapes, no epilogue; same box, same run"}
             tv = k["tave"]
             gbs = tv["total_work"] / max(tv["total_ms"] * 1e-3, 1e-12) / 1e9
             result["roofline_pool"] = {"bound": "hbm", "kernel": "tave_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",

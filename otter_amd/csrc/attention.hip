@@ -210,11 +210,7 @@ template <typename T, int NT, int LS, int NW = 4>
 int launch_d64(const AttnArgs& a, int n_seq, hipStream_t s) {
     constexpr int lds = NT * 16 * 128 * 2;
     auto kern = attn_d64<T, NT, LS, NW>;
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        configured = true;
-    }
+    if (int rc = otter_reserve_lds((const void*)kern, lds, "otter_attn_fwd_d64")) return rc;
     hipLaunchKernelGGL(kern, dim3(n_seq * a.heads), dim3(NW * 64), lds, s, a);
     OTTER_CHECK_LAUNCH("otter_attn_fwd_d64");
     return OTTER_OK;

@@ -31,6 +31,8 @@ enum OtterStatus {
 };
 
 void otter_set_error(const char* fmt, ...);   // defined in capi.hip (thread-local message)
+int otter_reserve_lds(const void* kernel, size_t bytes, const char* name);   // capi.hip: per (kernel, device) dynamic-LDS opt-in; OTTER_OK or error set
+int otter_cu_count(const char* name);                                       // capi.hip: CUs of the current device, 0 = error set
 
 #define OTTER_REQUIRE(cond, code, ...)                 \
     do {                                               \

@@ -200,11 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128(GemmArgs p) {
 template <typename T, int ACT, bool OUT_F32, bool RES>
 int launch(const GemmArgs& a, hipStream_t s) {
     auto kern = gemm_128x128<T, ACT, OUT_F32, RES>;
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        configured = true;
-    }
+    if (int rc = otter_reserve_lds((const void*)kern, 2 * STAGE_BYTES, "otter_gemm (128x128)")) return rc;
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), 2 * STAGE_BYTES, s, a);
     OTTER_CHECK_LAUNCH("otter_gemm");
     return OTTER_OK;

@@ -312,25 +312,9 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
 template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false>
 int launch256(const Gemm256Args& a, hipStream_t s) {
     auto kern = gemm_256x256<T, ACT, OUT_F32, RES, LNF>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) {
-            otter_set_error("otter_gemm (256x256): cannot reserve %d bytes of LDS: %s", LDS_BYTES, hipGetErrorString(e));
-            return OTTER_ERR_LAUNCH;
-        }
-        configured = true;
-    }
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            otter_set_error("otter_gemm (256x256): cannot query the device");
-            return OTTER_ERR_LAUNCH;
-        }
-        n_cu = prop.multiProcessorCount;
-    }
+    if (int rc = otter_reserve_lds((const void*)kern, LDS_BYTES, "otter_gemm (256x256)")) return rc;
+    const int n_cu = otter_cu_count("otter_gemm (256x256)");
+    if (n_cu <= 0) return OTTER_ERR_LAUNCH;
     const int tiles = a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDS_BYTES, s, a);
     OTTER_CHECK_LAUNCH("otter_gemm (256x256)");

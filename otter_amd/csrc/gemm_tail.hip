@@ -202,15 +202,7 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
 template <typename T, int ACT, bool OUT_F32, bool RES, int NS>
 int launch_tail_ns(const TailArgs& a, hipStream_t s) {
     auto kern = gemm_64x64<T, ACT, OUT_F32, RES, NS>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE);
-        if (e != hipSuccess) {
-            otter_set_error("otter_gemm (64x64): cannot reserve %d bytes of LDS: %s", NS * STAGE, hipGetErrorString(e));
-            return OTTER_ERR_LAUNCH;
-        }
-        configured = true;
-    }
+    if (int rc = otter_reserve_lds((const void*)kern, NS * STAGE, "otter_gemm (64x64)")) return rc;
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, a.partial ? a.k_splits : 1), dim3(256), NS * STAGE, s, a);
     OTTER_CHECK_LAUNCH("otter_gemm (64x64)");
     return OTTER_OK;

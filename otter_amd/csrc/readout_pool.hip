@@ -176,15 +176,7 @@ extern "C" int otter_readout_pool_fwd(const otter_readout_block* blocks, int n_b
                                        (size_t)readouts * heads * nk + (size_t)readouts * hidden);
     OTTER_REQUIRE(lds <= 160 * 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: needs %zu bytes of LDS (> 160 KiB)", lds);
     OTTER_REQUIRE((d * d) % 4 == 0 && (d * hidden) % 4 == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: d*d and d*hidden must be multiples of 4");
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)readout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            otter_set_error("otter_readout_pool_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            return OTTER_ERR_LAUNCH;
-        }
-        configured = lds;
-    }
+    if (int rc = otter_reserve_lds((const void*)readout_kernel, lds, "otter_readout_pool_fwd")) return rc;
     hipLaunchKernelGGL(readout_kernel, dim3(n_obs), dim3(256), lds, (hipStream_t)stream, a);
     OTTER_CHECK_LAUNCH("otter_readout_pool_fwd");
     return OTTER_OK;

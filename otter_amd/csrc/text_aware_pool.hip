@@ -275,15 +275,7 @@ template <typename T, int D, int NW, int NST, int WGS>
 int launch_tave_n(const TaveArgs& a, hipStream_t s) {
     constexpr int lds = NST * 16 * D * 2 + NW * (64 * 4 + 16) * 4;   // patch tiles (text image borrows one) + partial-tile exchange
     auto kern = tave_kernel<T, D, NW, NST, WGS>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            otter_set_error("otter_text_aware_pool_fwd: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
-            return OTTER_ERR_LAUNCH;
-        }
-        configured = true;
-    }
+    if (int rc = otter_reserve_lds((const void*)kern, lds, "otter_text_aware_pool_fwd")) return rc;
     hipLaunchKernelGGL(kern, dim3(a.units), dim3(NW * 64), lds, s, a);
     OTTER_CHECK_LAUNCH("otter_text_aware_pool_fwd");
     return OTTER_OK;

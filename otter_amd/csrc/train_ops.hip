@@ -573,15 +573,7 @@ extern "C" int otter_small_attn_bwd(const float* q, long sq_b, long sq_l, const 
     SmallAttn a{q, sq_b, sq_l, k, v, sk_b, sk_l, key_mask, sm_b, const_cast<float*>(dout), so_b, so_l, dq, dk, dv, sdq_b, sdq_l,
                 B, H, Lq, Lk, head_dim, causal ? 1 : 0, 1.0f / sqrtf((float)head_dim)};
     const size_t lds = sizeof(float) * (4 * SA_MAXL * SA_MAXD + 2 * SA_MAXL * SA_MAXL);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)small_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            otter_set_error("otter_small_attn_bwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            return OTTER_ERR_LAUNCH;
-        }
-        configured = true;
-    }
+    if (int rc = otter_reserve_lds((const void*)small_attn_bwd_kernel, lds, "otter_small_attn_bwd")) return rc;
     hipLaunchKernelGGL(small_attn_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
     OTTER_CHECK_LAUNCH("otter_small_attn_bwd");
     return OTTER_OK;
@@ -639,17 +631,9 @@ extern "C" int otter_text_aware_pool_temperature_grad(int dtype, const void* pat
     OTTER_REQUIRE(lds <= 160 * 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_temperature_grad: needs %zu bytes of LDS", lds);
     TaveGrad a{patches, unit_stride, dtype == DT_F16, text, pos, temperature, grad_out, partial, cams, P, D, K, t_rep, n_obs};
     hipStream_t s = (hipStream_t)stream;
-    static size_t configured[2] = {0, 0};
     const int which = dtype == DT_F16 ? 1 : 0;
     const void* fn = which ? (const void*)tave_temp_grad_kernel<_Float16> : (const void*)tave_temp_grad_kernel<__bf16>;
-    if (lds > configured[which]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            otter_set_error("otter_text_aware_pool_temperature_grad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            return OTTER_ERR_LAUNCH;
-        }
-        configured[which] = lds;
-    }
+    if (int rc = otter_reserve_lds(fn, lds, "otter_text_aware_pool_temperature_grad")) return rc;
     if (which) hipLaunchKernelGGL(tave_temp_grad_kernel<_Float16>, dim3(n_obs * cams), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(tave_temp_grad_kernel<__bf16>, dim3(n_obs * cams), dim3(256), lds, s, a);
     OTTER_CHECK_LAUNCH("otter_text_aware_pool_temperature_grad");

@@ -16,6 +16,7 @@ per-episode lengths (rows past an episode's length are zero and, by causality, n
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -25,6 +26,45 @@ from . import ops
 from .device_model import OtterDevice
 
 Tensor = torch.Tensor
+
+# A step of a few episodes is launch-bound (about 330 small kernels for the encoder of one observation): up to this many
+# images per step the encoder is captured once into a HIP graph and replayed.  OTTER_HIP_GRAPH=0 keeps it eager.
+GRAPH_MAX_IMAGES = 16
+_USE_GRAPH = os.environ.get("OTTER_HIP_GRAPH", "1") != "0"
+
+
+class _EncodeGraph:
+    """``OtterDevice.encode`` for one fixed set of input shapes, captured into a HIP graph: static input buffers, one
+    replay per step.  The weights' addresses are baked in, so the object lives and dies with its ``OtterDevice``."""
+
+    @staticmethod
+    def key_of(images: Tensor, text_feats: Tensor, proprio: Tensor, text_mask: Optional[Tensor]):
+        return (tuple(images.shape), images.dtype, tuple(text_feats.shape), tuple(proprio.shape),
+                None if text_mask is None else tuple(text_mask.shape))
+
+    def __init__(self, dev: OtterDevice, images: Tensor, text_feats: Tensor, proprio: Tensor, text_mask: Optional[Tensor]):
+        self.key = self.key_of(images, text_feats, proprio, text_mask)
+        d = dev.device
+        self.images, self.text, self.proprio = images.to(d).clone(), text_feats.to(d).clone(), proprio.to(d).clone()
+        self.mask = None if text_mask is None else text_mask.to(d).clone()
+        cur = torch.cuda.current_stream(d)
+        side = torch.cuda.Stream(device=d)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):              # once eagerly: LDS opt-ins, scratch buffers and allocator pools exist before capture
+            dev.encode(self.images, self.text, self.proprio, 1, self.mask)
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.out = dev.encode(self.images, self.text, self.proprio, 1, self.mask)
+
+    def __call__(self, images: Tensor, text_feats: Tensor, proprio: Tensor, text_mask: Optional[Tensor]) -> Tensor:
+        self.images.copy_(images, non_blocking=True)
+        self.text.copy_(text_feats, non_blocking=True)
+        self.proprio.copy_(proprio, non_blocking=True)
+        if self.mask is not None:
+            self.mask.copy_(text_mask, non_blocking=True)
+        self.graph.replay()
+        return self.out                            # overwritten by the next replay: consume it on this stream before then
 
 
 class BatchedRollout:
@@ -38,6 +78,7 @@ class BatchedRollout:
         self._cache = dev.policy.new_cache(self.n, self.S)
         self.lens_host = np.zeros(self.n, dtype=np.int64)
         self._lockstep = True
+        self._graph: Optional[_EncodeGraph] = None
 
     # ------------------------------------------------------------------ state
     @property
@@ -69,7 +110,12 @@ class BatchedRollout:
         Returns the action chunks, fp32 (n, horizon, action_dim), still on the device.
         """
         dev = self.dev
-        fresh = dev.encode(images, text_feats, proprio, 1, text_mask)            # (n, dim)
+        if _USE_GRAPH and images.shape[0] <= GRAPH_MAX_IMAGES and not torch.cuda.is_current_stream_capturing():
+            if self._graph is None or self._graph.key != _EncodeGraph.key_of(images, text_feats, proprio, text_mask):
+                self._graph = _EncodeGraph(dev, images, text_feats, proprio, text_mask)
+            fresh = self._graph(images, text_feats, proprio, text_mask)          # (n, dim), the graph's output buffer
+        else:
+            fresh = dev.encode(images, text_feats, proprio, 1, text_mask)        # (n, dim)
         nxt = self._cur ^ 1
         ops.window_append(self._win[self._cur], fresh, self._win[nxt], self._lens[self._cur], self._lens[nxt])
         self._cur = nxt

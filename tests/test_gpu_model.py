@@ -328,6 +328,31 @@ def test_otter_inference_end_to_end(dev, tmp_path, monkeypatch):
         policy({"image_primary": frames["image_primary"]}, prompt, pose, grip)              # a camera is missing
 
 
+def test_small_batch_encoder_graph_matches_eager(dev, monkeypatch):
+    """Steps of a few episodes replay a captured HIP graph of the encoder (launch-bound otherwise): same bits as the eager
+    launches over a rollout across the window boundary, with fresh inputs every step and a new graph when the shapes change."""
+    from otter_amd import engine
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, _ = _model(mc, sc, case["seed"], dev)
+    dm = model.device_model()
+    cams, res = len(model.camera_keys), sc.image_size
+    g = torch.Generator().manual_seed(11)
+    for n in (2, 1):
+        ro_graph, ro_eager = engine.BatchedRollout(dm, n), engine.BatchedRollout(dm, n)
+        for _ in range(sc.seq_length + 3):
+            imgs = torch.randint(0, 256, (n * cams, 3, res, res), dtype=torch.uint8, generator=g).to(dev)
+            tf = torch.randn(n, mc.first_k_tokens, dm.clip.embed, generator=g).to(dev)
+            prop = torch.randn(n, mc.proprio_input_dim, generator=g).to(dev)
+            monkeypatch.setattr(engine, "_USE_GRAPH", True)
+            got = ro_graph.step(imgs, tf, prop).clone()
+            monkeypatch.setattr(engine, "_USE_GRAPH", False)
+            ref = ro_eager.step(imgs, tf, prop)
+            assert torch.equal(got, ref)
+        assert ro_graph._graph is not None and ro_eager._graph is None
+        assert ro_graph._graph.key[0] == (n * cams, 3, res, res)
+
+
 def test_bf16_towers_and_batch_independence(dev):
     """bfloat16 operands for the towers (the alternative to the fp16 default): visual tokens still reach cosine 0.9999
     against the fp32 oracle; actions carry bf16's 8x larger rounding (documented bound 4e-3, the fp16 default is held

@@ -45,38 +45,47 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const T* x, long ldx, float
 }
 
 // ---------------------------------------------------------------- y = act(x Wt + b), fp32, small shapes
-// Wt is [K][N] (transposed weight).  One workgroup handles 8 rows; x rows are staged in LDS.
+// Wt is [K][N] (transposed weight).  One workgroup handles 8 rows x 64 columns; x rows are staged in LDS.  These calls
+// have one to a few rows (the proprioception MLP of a rollout step), so the time is the chain of dependent weight loads:
+// each of the 4 waves sums a quarter of K for the 64 columns (coalesced 256-byte weight reads, 16 loads in flight per
+// lane), the four partial sums are added in wave order through LDS (deterministic).
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, long ldx, const float* wt, const float* bias,
                                                          float* y, long ldy, int M, int N, int K, int act) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];   // [8][K]
-    const int r0 = blockIdx.x * 8;
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [8][K], then [4][8][64] partial sums
+    float* red = xs + 8 * K;
+    const int r0 = blockIdx.x * 8, n0 = blockIdx.y * 64;
     const int nr = min(8, M - r0);
     for (int i = threadIdx.x; i < 8 * K; i += 256) {
         const int r = i / K, k = i % K;
         xs[i] = (r < nr) ? x[(long)(r0 + r) * ldx + k] : 0.f;
     }
     __syncthreads();
-    for (int n = threadIdx.x; n < N; n += 256) {
-        float acc[8];
-        const float b = bias ? bias[n] : 0.f;
+    const int c = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int n = min(n0 + c, N - 1);                         // columns past N repeat the last one and are not stored
+    const int kq = (K + 3) / 4;
+    const int k0 = ks * kq, k1 = min(K, k0 + kq);
+    float acc[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = b;
-#pragma unroll 8
-        for (int k = 0; k < K; ++k) {                 // 8 independent weight loads in flight per thread
-            const float w = wt[(long)k * N + n];
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+#pragma unroll 16
+    for (int k = k0; k < k1; ++k) {
+        const float w = wt[(long)k * N + n];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] += xs[r * K + k] * w;
-        }
+        for (int r = 0; r < 8; ++r) acc[r] += xs[r * K + k] * w;
+    }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (r < nr) {
-                float v = acc[r];
-                if (act == OTTER_EPI_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (act == OTTER_EPI_ACT_GELU) v = gelu_erf(v);
-                else if (act == OTTER_EPI_ACT_QUICKGELU) v = quick_gelu(v);
-                y[(long)(r0 + r) * ldy + n] = v;
-            }
-        }
+    for (int r = 0; r < 8; ++r) red[(ks * 8 + r) * 64 + c] = acc[r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+        const int r = i >> 6, cc = i & 63;
+        if (r >= nr || n0 + cc >= N) continue;
+        float v = bias ? bias[n0 + cc] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v += red[(q * 8 + r) * 64 + cc];
+        if (act == OTTER_EPI_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == OTTER_EPI_ACT_GELU) v = gelu_erf(v);
+        else if (act == OTTER_EPI_ACT_QUICKGELU) v = quick_gelu(v);
+        y[(long)(r0 + r) * ldy + n0 + cc] = v;
     }
 }
 
@@ -180,7 +189,10 @@ extern "C" int otter_linear_f32(const float* x, long ldx, const float* wt, const
     if (M == 0) return OTTER_OK;
     OTTER_REQUIRE(M > 0 && N > 0 && K > 0 && K <= 2048, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_linear_f32: M=%d N=%d K=%d (K <= 2048)", M, N, K);
     OTTER_REQUIRE(ldx >= K && ldy >= N, OTTER_ERR_INVALID_ARGUMENT, "otter_linear_f32: leading dimensions too small");
-    hipLaunchKernelGGL(linear_f32_kernel, dim3((M + 7) / 8), dim3(256), sizeof(float) * 8 * K, (hipStream_t)stream,
+    const size_t lds = sizeof(float) * (8 * (size_t)K + 4 * 8 * 64);
+    if (lds > 64 * 1024)
+        if (int rc = otter_reserve_lds((const void*)linear_f32_kernel, lds, "otter_linear_f32")) return rc;
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((M + 7) / 8, (N + 63) / 64), dim3(256), lds, (hipStream_t)stream,
                        x, ldx, wt, bias, y, ldy, M, N, K, act);
     OTTER_CHECK_LAUNCH("otter_linear_f32");
     return OTTER_OK;

@@ -254,6 +254,9 @@ def main():
                     help="infer: batched rollout (the headline metric); train: one data-parallel training step per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-reference-points", action="store_true",
+                    help="skip the two side measurements (vendor-library GEMM rate, pooling kernel at a chip-filling size): profiles of "
+                         "the step then hold the step's kernels only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -314,7 +317,7 @@ def main():
                                   "algorithmic_bytes_per_launch": gm["total_bytes"] / gm["launches"], "pmc_mfma_busy_frac": mfma_busy,
                                   "launches": gm["launches"], "avg_launch_us": 1e3 * gm["total_ms"] / gm["launches"],
                                   "gemm_ms_per_step": gm["total_ms"] / 2}
-            if world == 1 and args.workload == "infer":
+            if world == 1 and args.workload == "infer" and not args.no_reference_points:
                 lib_tf = library_gemm_rate(device, clip_dtype)
                 result["roofline"]["vendor_library_plain_product"] = {"tflops": lib_tf, "frac_of_peak": lib_tf / PEAK_BF16_TFLOPS,
                                                                        "note": "torch.mm (hipBLASLt) on the block's four shapes, no epilogue; same box, same run"}
@@ -324,7 +327,7 @@ def main():
                                        "frac": gbs / PEAK_HBM_GBS, "traffic": None, "launches": tv["launches"],
                                        "avg_launch_us": 1e3 * tv["total_ms"] / tv["launches"],
                                        "units_per_launch": 2 * work.n}
-            if world == 1 and args.workload == "infer":
+            if world == 1 and args.workload == "infer" and not args.no_reference_points:
                 result["roofline_pool"]["saturated"] = pool_saturated(device, clip_dtype)
         if world == 1 and not args.no_cpu_baseline and args.workload == "infer":
             result["cpu_baseline"] = cpu_baseline(work)

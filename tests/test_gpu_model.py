@@ -328,6 +328,48 @@ def test_otter_inference_end_to_end(dev, tmp_path, monkeypatch):
         policy({"image_primary": frames["image_primary"]}, prompt, pose, grip)              # a camera is missing
 
 
+def test_otter_inference_sim_end_to_end(dev, tmp_path, monkeypatch):
+    """The simulator interface (``otter_interface.py:188-307``): frames already at the model's resolution (``to_tensor`` +
+    normalisation only), the 10-d proprioception passed through, delta chunks returned as predicted; against the CPU
+    oracle across the window boundary, then ``reset()``."""
+    from PIL import Image
+    from otter_amd import tokenizer as tk
+    from otter_amd.checkpoint import save_checkpoint
+    from otter_amd.config import ExperimentConfig
+    from otter_amd.otter_interface import OtterInferenceSim
+    from otter_amd.vision_tf import pil_to_uint8_chw
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], torch.device("cpu"))
+    save_checkpoint(model, ExperimentConfig(model_cfg=mc, shared_cfg=sc), str(tmp_path), 7)
+    bpe = tmp_path / "merges.txt"
+    _write_synthetic_merges(str(bpe))
+    monkeypatch.setenv("OTTER_CLIP_BPE", str(bpe))
+    monkeypatch.setattr(tk, "_default", None)
+    policy = OtterInferenceSim(str(tmp_path), 7, device="cuda")
+    prompt = "pick up the cube"
+    ids = tk.tokenize([prompt])[0]
+    rng = np.random.default_rng(5)
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length)
+    ro = R.Rollout(sd, dims)
+    worst = 0.0
+    for step in range(sc.seq_length + 2):
+        frames = {k: Image.fromarray(rng.integers(0, 256, (sc.image_size, sc.image_size, 3), dtype=np.uint8)) for k in policy.model.camera_keys}
+        prop = rng.standard_normal(mc.proprio_input_dim)
+        got = policy(frames, prompt, prop)
+        assert isinstance(got, np.ndarray) and got.shape == (sc.action_horizon, mc.action_dim)
+        imgs = torch.stack([pil_to_uint8_chw(frames[k]) for k in policy.model.camera_keys])
+        ref = ro.step(R.clip_transform(imgs), ids, torch.tensor(prop).float()).numpy()
+        worst = max(worst, float(np.abs(got - ref).max()))
+    print(f"OtterInferenceSim end to end: max |action - oracle| = {worst:.2e}")
+    assert worst <= 1e-3
+    policy.reset()
+    assert policy.model.cache_size == 0
+    with pytest.raises(AssertionError):
+        policy({"image_primary": frames["image_primary"]}, prompt, prop)                    # a camera is missing
+
+
 def test_small_batch_encoder_graph_matches_eager(dev, monkeypatch):
     """Steps of a few episodes replay a captured HIP graph of the encoder (launch-bound otherwise): same bits as the eager
     launches over a rollout across the window boundary, with fresh inputs every step and a new graph when the shapes change."""

@@ -468,3 +468,33 @@ def test_text_aware_pool_convexity_at_bench_size(dev):
     direction = patches[7, 0].half().float()
     direction = direction / direction.norm()
     torch.testing.assert_close(centred[cam, m], direction.expand(K, D), rtol=0, atol=3e-3)
+
+
+def test_torch_custom_ops_match_the_wrappers(dev):
+    """``torch.ops.otter_hip.*`` run the same kernels as :mod:`otter_amd.ops` (bit-identical results)."""
+    import otter_amd.torch_ops  # noqa: F401
+    from otter_amd import ops
+    ns = torch.ops.otter_hip
+    dt = torch.float16
+    a = _randn(91, 300, 128).to(dev).to(dt)
+    wp = ops.pack_weight(_randn(92, 248, 128).to(dev) / 11.0, dt)
+    bias = _randn(93, 248).to(dev)
+    res = _randn(94, 300, 248).to(dev)
+    assert torch.equal(ns.gemm(a, wp, 248, bias, ACTS["quickgelu"], False, None), ops.gemm(a, wp, 248, bias, act=ACTS["quickgelu"]))
+    assert torch.equal(ns.gemm(a, wp, 248, bias, 0, False, res), ops.gemm(a, wp, 248, bias, residual=res))
+    x = _randn(95, 37, 768).to(dev)
+    g, b = _randn(96, 768).to(dev), _randn(97, 768).to(dev)
+    assert torch.equal(ns.layernorm(x, g, b, 1e-5, 1), ops.layernorm(x, g, b, out_dtype=dt))
+    qkv = _randn(98, 2 * 50, 3 * 128).to(dev).to(dt)
+    assert torch.equal(ns.attn_fwd_d64(qkv, 2, 50, 2, False), ops.attn_d64(qkv, 2, 50, 2, False))
+    cache = _randn(99, 3, 12, 3 * 96).to(dev)
+    assert torch.equal(ns.attn_policy(cache, 1, 5, 2), ops.attn_policy(cache, 1, 5, 2))
+    pos = _randn(100, 49, 512).to(dev)
+    packed = ns.pos_emb_pack(pos, 1)
+    assert torch.equal(packed, ops.pos_emb_pack(pos, dt))
+    patches = _randn(101, 4, 50, 512).to(dev).to(dt)
+    text = _randn(102, 2, 15, 512).to(dev)
+    pk = torch.stack([packed, packed])
+    temp = torch.full((2,), 0.07, device=dev)
+    assert torch.equal(ns.text_aware_pool(patches, text, pk, temp, 2, 2, 1, 49), ops.text_aware_pool(patches, text, pk, temp, 2, 2, 1, n_patches=49))
+    assert torch.equal(ns.l2norm_rows(x), ops.l2norm_rows(x))

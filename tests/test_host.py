@@ -369,3 +369,24 @@ def test_resize_arithmetic_is_pil_bicubic_bit_for_bit(h, w, size):
     want = pil_to_uint8_chw(crop2square(Image.fromarray(frame)).resize((size, size), Image.Resampling.BICUBIC)).numpy()
     got = crop_resize_reference_arithmetic(frame, size)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_torch_custom_ops_are_registered_and_have_no_cpu_implementation():
+    """``torch.ops.otter_hip.*``: schemas, shape inference on meta tensors, and a loud failure on CPU tensors."""
+    import otter_amd.torch_ops  # noqa: F401
+    ns = torch.ops.otter_hip
+    for name in ("gemm", "layernorm", "attn_fwd_d64", "attn_policy", "pos_emb_pack", "text_aware_pool", "l2norm_rows"):
+        assert hasattr(ns, name)
+    meta = lambda *shape, dtype=torch.float16: torch.empty(*shape, dtype=dtype, device="meta")          # noqa: E731
+    y = ns.gemm(meta(300, 128), meta(256, 128), 256, None, 1, False, None)
+    assert tuple(y.shape) == (300, 256) and y.dtype == torch.float16
+    y = ns.gemm(meta(300, 128), meta(256, 128), 250, None, 0, False, meta(300, 250, dtype=torch.float32))
+    assert tuple(y.shape) == (300, 250) and y.dtype == torch.float32
+    assert ns.layernorm(meta(7, 64, dtype=torch.float32), None, None, 1e-5, 0).dtype == torch.bfloat16
+    assert tuple(ns.attn_fwd_d64(meta(2 * 257, 3 * 1024), 2, 257, 16, False).shape) == (514, 1024)
+    assert tuple(ns.attn_policy(meta(3, 12, 3 * 768, dtype=torch.float32), 1, 4, 8).shape) == (3, 768)
+    assert tuple(ns.pos_emb_pack(meta(196, 512, dtype=torch.float32), 1).shape) == (208 * 512,)
+    y = ns.text_aware_pool(meta(4, 257, 768), meta(2, 15, 768, dtype=torch.float32), meta(2, 256 * 768), meta(2, dtype=torch.float32), 2, 2, 1, 256)
+    assert tuple(y.shape) == (2, 2, 15, 768) and y.dtype == torch.float32
+    with pytest.raises(NotImplementedError):
+        ns.l2norm_rows(torch.randn(3, 8))

@@ -113,8 +113,8 @@ def measure_kernels(work, steps: int):
     """Per-launch device time of the GEMM and pooling kernels over `steps` extra steps, with HIP events recorded on
     the stream the kernels run on (torch's current stream)."""
     from otter_amd import ops
-    rec = {"gemm": [], "tave": []}
-    real_gemm, real_tave = ops.gemm, ops.text_aware_pool
+    rec = {"gemm": [], "tave": [], "stats": []}
+    real_gemm, real_tave, real_stats = ops.gemm, ops.text_aware_pool, ops.row_stats
 
     def timed(kind, fn, flops_or_bytes):
         def wrapper(*a, **k):
@@ -162,12 +162,14 @@ def measure_kernels(work, steps: int):
 
     ops.gemm = gemm_wrapper
     ops.text_aware_pool = timed("tave", real_tave, tave_bytes)
+    # row statistics of the folded LayerNorms: one read of the residual stream, 8 bytes out per row
+    ops.row_stats = timed("stats", real_stats, lambda a, k, out: a[0].numel() * a[0].element_size() + out.numel() * 4)
     try:
         for _ in range(steps):
             work.step()
         torch.cuda.synchronize()
     finally:
-        ops.gemm, ops.text_aware_pool = real_gemm, real_tave
+        ops.gemm, ops.text_aware_pool, ops.row_stats = real_gemm, real_tave, real_stats
     out = {}
     for kind, items in rec.items():
         ms = [e0.elapsed_time(e1) for e0, e1, _, _ in items]
@@ -327,6 +329,12 @@ def main():
                                        "frac": gbs / PEAK_HBM_GBS, "traffic": None, "launches": tv["launches"],
                                        "avg_launch_us": 1e3 * tv["total_ms"] / tv["launches"],
                                        "units_per_launch": 2 * work.n}
+            st = k["stats"]
+            if st["launches"]:
+                sg = st["total_work"] / max(st["total_ms"] * 1e-3, 1e-12) / 1e9
+                result["roofline_layernorm"] = {"bound": "hbm", "kernel": "ln_rows (row statistics of the LayerNorms folded into the GEMMs)",
+                                                "achieved": sg, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sg / PEAK_HBM_GBS,
+                                                "launches": st["launches"], "avg_launch_us": 1e3 * st["total_ms"] / st["launches"]}
             if world == 1 and args.workload == "infer" and not args.no_reference_points:
                 result["roofline_pool"]["saturated"] = pool_saturated(device, clip_dtype)
         if world == 1 and not args.no_cpu_baseline and args.workload == "infer":

@@ -113,6 +113,51 @@ __global__ __launch_bounds__(256) void ln_rows(LnArgs p) {
     }
 }
 
+// Row statistics of a 16-bit residual stream (width <= 1024, a multiple of 8): the only work is one read of x, taken 16
+// bytes per lane and load (ln_rows reads 8).  R rows per wave, all their loads in flight before the first reduction;
+// measured on 32896 x 1024 fp16: R = 1: 11.7 us (5.7 TB/s), 2: 12.2, 3: 12.9, 4: 13.7, 8: 17.5; ln_rows: 15.9.
+// Two-pass mean / variance on the registers, as ln_rows.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void row_stats16(const T* x, long ldx, float* stats, int rows, int width, float eps) {
+    typedef typename Half16<T>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    const int nvec = width >> 3;
+    v8 v[R][2];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const T* src = x + (long)min(row0 + r, rows - 1) * ldx;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[r][i][e] = Half16<T>::from(0.f);
+            if (idx < nvec) v[r][i] = *(const v8*)(src + idx * 8);
+        }
+    }
+    const float inv_w = 1.0f / (float)width;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[r][i][e];
+        const float mean = wave_sum(sum) * inv_w;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i * 64 + lane < nvec) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)v[r][i][e] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) * inv_w + eps);
+        if (lane == 0 && row0 + r < rows) *(f32x2*)(stats + 2 * (long)(row0 + r)) = (f32x2){mean, rstd};
+    }
+}
+
 template <int SRC, int IN_DT, int OUT_DT, bool NORMALISE>
 int launch_ln(const LnArgs& a, hipStream_t s, const char* name) {
     const int grid = (a.rows + 3) / 4;
@@ -205,6 +250,14 @@ extern "C" int otter_row_stats(const void* x, int in_dtype, long ldx, float* sta
     LnArgs a{};
     a.x = x; a.ldx = ldx; a.y = stats; a.ldy = 2; a.rows = rows; a.width = width; a.eps = eps;
     hipStream_t s = (hipStream_t)stream;
+    if ((in_dtype == DT_BF16 || in_dtype == DT_F16) && width % 8 == 0 && width <= 1024 && ldx % 8 == 0) {
+        constexpr int R = 1;
+        const int grid = (rows + 4 * R - 1) / (4 * R);
+        if (in_dtype == DT_BF16) hipLaunchKernelGGL((row_stats16<__bf16, R>), dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldx, stats, rows, width, eps);
+        else hipLaunchKernelGGL((row_stats16<_Float16, R>), dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldx, stats, rows, width, eps);
+        OTTER_CHECK_LAUNCH("otter_row_stats");
+        return OTTER_OK;
+    }
     if (in_dtype == DT_F32) return launch_ln<SRC_PLAIN, DT_F32, DT_STATS, true>(a, s, "otter_row_stats");
     if (in_dtype == DT_BF16) return launch_ln<SRC_PLAIN, DT_BF16, DT_STATS, true>(a, s, "otter_row_stats");
     if (in_dtype == DT_F16) return launch_ln<SRC_PLAIN, DT_F16, DT_STATS, true>(a, s, "otter_row_stats");

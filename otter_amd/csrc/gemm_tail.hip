@@ -253,13 +253,32 @@ struct ReduceArgs {
     const float* ln_stats; const float* ln_colsum;
 };
 
+template <int SP>
+__device__ __forceinline__ f32x4 sum_partials(const float* part, long stride) {
+    f32x4 pv[SP];
+#pragma unroll
+    for (int s = 0; s < SP; ++s) pv[s] = *(const f32x4*)(part + s * stride);
+    f32x4 v = pv[0];
+#pragma unroll
+    for (int s = 1; s < SP; ++s) v += pv[s];
+    return v;
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce(ReduceArgs p) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = p.N >> 2;
     if (i >= (long)p.M * nq) return;
     const int m = (int)(i / nq), n = (int)(i % nq) * 4;
+    // all partial products in flight at once (a loop with a run-time bound waits out one memory round trip per split),
+    // summed in split order
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.splits; ++s) v += *(const f32x4*)(p.partial + ((long)s * p.M + m) * p.N + n);
+    const float* part = p.partial + (long)m * p.N + n;
+    const long stride = (long)p.M * p.N;
+    if (p.splits == 8) v = sum_partials<8>(part, stride);
+    else if (p.splits == 4) v = sum_partials<4>(part, stride);
+    else if (p.splits == 2) v = sum_partials<2>(part, stride);
+    else
+        for (int s = 0; s < p.splits; ++s) v += *(const f32x4*)(part + s * stride);
     if (p.ln_stats) {
         const f32x2 st = *(const f32x2*)(p.ln_stats + 2 * (long)m);
         v = (v - st[0] * *(const f32x4*)(p.ln_colsum + n)) * st[1];

@@ -332,7 +332,7 @@ def main():
             st = k["stats"]
             if st["launches"]:
                 sg = st["total_work"] / max(st["total_ms"] * 1e-3, 1e-12) / 1e9
-                result["roofline_layernorm"] = {"bound": "hbm", "kernel": "ln_rows (row statistics of the LayerNorms folded into the GEMMs)",
+                result["roofline_layernorm"] = {"bound": "hbm", "kernel": "row_stats16 (row statistics of the LayerNorms folded into the GEMMs)",
                                                 "achieved": sg, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sg / PEAK_HBM_GBS,
                                                 "launches": st["launches"], "avg_launch_us": 1e3 * st["total_ms"] / st["launches"]}
             if world == 1 and args.workload == "infer" and not args.no_reference_points:

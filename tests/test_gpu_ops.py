@@ -498,3 +498,18 @@ def test_torch_custom_ops_match_the_wrappers(dev):
     temp = torch.full((2,), 0.07, device=dev)
     assert torch.equal(ns.text_aware_pool(patches, text, pk, temp, 2, 2, 1, 49), ops.text_aware_pool(patches, text, pk, temp, 2, 2, 1, n_patches=49))
     assert torch.equal(ns.l2norm_rows(x), ops.l2norm_rows(x))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("rows,width,pad", [(5, 768, 0), (1031, 1024, 64), (64, 8, 8), (3, 520, 0), (130, 2048, 0)])
+def test_row_stats_shapes(dev, rows, width, pad, dtype):
+    """Row statistics over ragged row counts, widths on both sides of the 16-bit kernel's limits, and strided rows."""
+    from otter_amd import ops
+    dt = DTYPES[dtype]
+    big = torch.zeros(rows, width + pad, dtype=dt, device=dev)
+    x = big[:, :width]
+    x.copy_((_randn(110, rows, width) * 1.7 - 0.4).to(dt))
+    st = ops.row_stats(x)
+    xf = x.float()
+    torch.testing.assert_close(st[:, 0], xf.mean(-1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(st[:, 1], (xf.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=2e-5, atol=1e-5)

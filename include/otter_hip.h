@@ -61,7 +61,8 @@ int otter_gemm(int dtype, const void* A, long lda, const void* W, int n_pad, con
 int otter_gemm_ln(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const float* row_stats,
                   const float* col_sum, void* C, long ldc, int M, int N, int K, int epilogue, void* stream);
 /* otter_gemm / otter_gemm_ln with a caller-provided scratch buffer (row_stats / col_sum NULL = no folded LayerNorm).
- * With it the < 256 remainder rows of a big 16-bit problem (the CLIP towers have 32896 = 128 x 257 token rows) are
+ * With it few-tile problems (a rollout step of one episode) and the < 256 remainder rows of a big 16-bit problem (the
+ * CLIP towers have 32896 = 128 x 257 token rows) are
  * multiplied split-K over the whole chip: fp32 partial products go to `workspace`, a second launch sums them and applies
  * the epilogue.  workspace: >= otter_gemm_workspace_floats(N) floats, 16-byte aligned, private to the stream for the
  * duration of the call; NULL = as otter_gemm.  Results are deterministic (fixed summation order). */

@@ -240,9 +240,11 @@ int dispatch(const GemmArgs& a, int act, bool out_f32, bool res, hipStream_t s) 
 // splitting does not reduce, and the second launch is pure cost (measured on 514 rows x 1024 columns, 144 tiles: 14.9 us +
 // 4.8 us split in two against 12 us in one pass).
 static int pick_splits(int dtype, int M, int N, int K, const float* workspace, long workspace_floats) {
-    if (!workspace || dtype == DT_F32 || N % 8 != 0) return 1;
-    const int nk = K / 64, tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    if (tiles > 128) return 1;
+    if (!workspace || N % 8 != 0) return 1;
+    const int nk = K / (dtype == DT_F32 ? 32 : 64), tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    // fp32 (policy transformer, heads): only the few-row launches of a rollout step with one or a few episodes, whose K loop
+    // is a chain of 24+ dependent K-steps on a handful of CUs; with more tiles the fp32 MFMA rate is the bound
+    if (tiles > (dtype == DT_F32 ? 48 : 128)) return 1;
     for (int sp = 8; sp > 1; sp >>= 1)
         if (nk % sp == 0 && nk / sp >= 2 && tiles * sp <= 512 && (long)sp * M * N <= workspace_floats) return sp;
     return 1;

@@ -320,13 +320,15 @@ __global__ __launch_bounds__(256) void splitk_reduce(ReduceArgs p) {
 
 // Split-K for problems with too few 64x64 tiles to occupy the chip (the < 256 remainder rows of the tower GEMMs: 32
 // tiles, each pulling 1 MB through one CU): `splits` workgroups per tile write fp32 partial products to `workspace`
-// ([splits][M][N] floats, caller-provided), a second launch sums them and applies the epilogue.  16-bit operands only.
+// ([splits][M][N] floats, caller-provided), a second launch sums them and applies the epilogue.
 int otter_gemm64_splitk_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                                void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
                                const float* ln_colsum, float* workspace, int splits, hipStream_t s) {
     TailArgs a{(const char*)A, lda, (const char*)W, nullptr, nullptr, 0, nullptr, 0, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB,
                nullptr, nullptr, splits, workspace};
-    int rc = dtype == DT_BF16 ? launch_tail_ns<__bf16, ACT_NONE, true, false, 4>(a, s) : launch_tail_ns<_Float16, ACT_NONE, true, false, 4>(a, s);
+    int rc = dtype == DT_BF16 ? launch_tail_ns<__bf16, ACT_NONE, true, false, 4>(a, s)
+             : dtype == DT_F16 ? launch_tail_ns<_Float16, ACT_NONE, true, false, 4>(a, s)
+                               : launch_tail_ns<float, ACT_NONE, true, false, 4>(a, s);
     if (rc != OTTER_OK) return rc;
     ReduceArgs r{workspace, splits, bias, residual, ldr, C, ldc, M, N, act, out_f32 ? DT_F32 : dtype, res ? 1 : 0, ln_stats, ln_colsum};
     const long threads = (long)M * (N / 4);

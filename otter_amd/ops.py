@@ -98,7 +98,7 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
     """out[M, n] = epilogue(a[M, K] @ w[n, K]^T + bias); operands bf16 / fp16 / fp32 (``w_packed`` from
     :func:`pack_weight` with the same dtype); output the operand type, or fp32 (``out_f32``, an fp32 residual, fp32
     operands).  ``residual`` (fp32, or the operands' 16-bit type) is added after the bias and fixes the output type.
-    ``split_k``: few-tile 16-bit problems and the < 256 remainder rows of big ones may be multiplied split-K through a
+    ``split_k``: few-tile problems and the < 256 remainder rows of big 16-bit ones may be multiplied split-K through a
     scratch buffer (deterministic; rows can differ from the one-pass kernels in the last bit of the fp32 sum)."""
     dt = _dt(a.dtype, "gemm.a")
     _chk(a, a.dtype, "gemm.a")
@@ -140,7 +140,7 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         if tuple(ln_stats.shape) != (m, 2) or ln_colsum.numel() < n or not ln_stats.is_contiguous():
             raise ValueError("gemm: ln_stats must be (M, 2) contiguous and ln_colsum at least N long")
     # scratch for the split-K pass over the remainder rows of a big 16-bit problem (one buffer per device and stream)
-    ws = _gemm_workspace(a.device, n) if (split_k and _SPLIT_K and a.dtype != torch.float32 and (m % 256 != 0 or m < 1024)) else None
+    ws = _gemm_workspace(a.device, n) if (split_k and _SPLIT_K and (m < 256 if a.dtype == torch.float32 else (m % 256 != 0 or m < 1024))) else None
     _lib.call("otter_gemm_ws", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
               _ptr(ln_stats), _ptr(ln_colsum), _ptr(out), ldc, m, n, k, epi, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     return out

@@ -73,10 +73,12 @@ class OTTER(nn.Module):
         self._clip_key = None
         self._tail = None
         self._rollout: Optional[BatchedRollout] = None
+        self._param_groups = None
         self.cache_size = 0
 
     # ------------------------------------------------------------------ device state
     def _apply(self, fn, *a, **k):
+        self._param_groups = None
         self._dev = None
         self._clip_dev = None
         self._tail = None
@@ -84,13 +86,20 @@ class OTTER(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
+        self._param_groups = None
         self._dev = None
         self._clip_dev = None
         self._rollout = None
         return super().load_state_dict(*a, **k)
 
     def _weights_key(self, trainable: bool):
-        return tuple((p.data_ptr(), p._version) for n, p in self.named_parameters() if n.startswith("clip_model.") != trainable)
+        """Changes whenever a parameter of the group is written in place (optimizer step, ``copy_``); moves and
+        ``load_state_dict`` drop the packed copies directly.  Called on every forward: the parameter lists are cached (the
+        module tree is fixed after construction) so that the check costs one attribute read per tensor."""
+        if self._param_groups is None:
+            named = list(self.named_parameters())
+            self._param_groups = ([p for n, p in named if n.startswith("clip_model.")], [p for n, p in named if not n.startswith("clip_model.")])
+        return tuple(p._version for p in self._param_groups[1 if trainable else 0])
 
     def _device(self) -> torch.device:
         device = self.input_projection.weight.device
@@ -157,8 +166,8 @@ class OTTER(nn.Module):
             flat = flat.float()
         return flat.contiguous(), b, t
 
-    def _text_feats(self, text: Tensor) -> Tensor:
-        dev = self.device_model()
+    def _text_feats(self, text: Tensor, dev: Optional[OtterDevice] = None) -> Tensor:
+        dev = dev if dev is not None else self.device_model()
         ids = text.detach().to("cpu", torch.int32)
         if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.clip_arch.vocab_size):
             raise ValueError("token id outside the CLIP vocabulary")
@@ -218,7 +227,7 @@ class OTTER(nn.Module):
         ro = self._get_rollout()
         dev = ro.dev
         imgs = images if images.dtype == torch.uint8 else images.float()
-        tf_raw = self._text_feats(text.view(1, -1))
+        tf_raw = self._text_feats(text.view(1, -1), dev)
         mask = text_mask.view(1, -1) if (self.pool_true_text and text_mask is not None) else None
         out = ro.step(imgs.to(dev.device).contiguous(), tf_raw, proprio.view(1, -1).to(dev.device, torch.float32).contiguous(), mask)
         self.cache_size = int(ro.lens_host[0])

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 8
+#define OTTER_HIP_ABI_VERSION 9
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -70,6 +70,16 @@ long otter_gemm_workspace_floats(int N);
 int otter_gemm_ws(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const void* residual,
                   long ldr, const float* row_stats, const float* col_sum, void* C, long ldc, int M, int N, int K, int epilogue,
                   float* workspace, long workspace_floats, void* stream);
+/* otter_gemm_ws for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): the split-K scratch is a static device array inside the library (33.4 MB per GPU,
+ * held until the process ends), so no workspace is passed and the call allocates nothing.  No counterpart in the
+ * reference.  N <= otter_gemm_static_ws_max_n() (4096), larger N is rejected with OTTER_ERR_UNSUPPORTED_SHAPE; results
+ * are bit-identical to otter_gemm_ws with a workspace of otter_gemm_workspace_floats(N) floats.  Every call on one GPU
+ * shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race; serialise them. */
+long otter_gemm_static_ws_max_n(void);
+int otter_gemm_static_ws(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const void* residual,
+                         long ldr, const float* row_stats, const float* col_sum, void* C, long ldc, int M, int N, int K,
+                         int epilogue, void* stream);
 /* stats[r] = (mean, 1/sqrt(var + eps)) of row r (two-pass, fp32), x fp32 or 16-bit. */
 int otter_row_stats(const void* x, int in_dtype, long ldx, float* stats, int rows, int width, float eps, void* stream);
 

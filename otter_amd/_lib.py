@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
@@ -36,6 +36,7 @@ _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
 _SIGNATURES = {
     "otter_gemm": [_I, _P, _L, _P, _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "otter_gemm_ws": [_I, _P, _L, _P, _I, _P, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P],
+    "otter_gemm_static_ws": [_I, _P, _L, _P, _I, _P, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "otter_gemm_ln": [_I, _P, _L, _P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "otter_row_stats": [_P, _I, _L, _P, _I, _I, _F, _P],
     "otter_layernorm": [_P, _I, _L, _P, _P, _P, _L, _I, _I, _F, _I, _P],
@@ -99,6 +100,8 @@ def load() -> ctypes.CDLL:
     lib.otter_pos_emb_packed_elems.argtypes = [c_int, c_int]
     lib.otter_gemm_workspace_floats.restype = c_long
     lib.otter_gemm_workspace_floats.argtypes = [c_int]
+    lib.otter_gemm_static_ws_max_n.restype = c_long
+    lib.otter_gemm_static_ws_max_n.argtypes = []
     _lib = lib
     return lib
 
@@ -112,4 +115,4 @@ def call(name: str, *args) -> None:
 
 def exported_names():
     return sorted(list(_SIGNATURES) + ["otter_last_error", "otter_hip_abi_version", "otter_grad_stats_workspace_floats",
-                                            "otter_pos_emb_packed_elems", "otter_gemm_workspace_floats"])
+                                            "otter_pos_emb_packed_elems", "otter_gemm_workspace_floats", "otter_gemm_static_ws_max_n"])

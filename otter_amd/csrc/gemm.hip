@@ -20,6 +20,9 @@
 #include "common.hpp"
 #include "otter_hip.h"
 
+#include <map>
+#include <mutex>
+
 // 256x256-tile kernel for the big 16-bit shapes (gemm256.hip)
 bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc);
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
@@ -335,4 +338,49 @@ extern "C" int otter_gemm_ws(int dtype, const void* A, long lda, const void* W, 
     OTTER_REQUIRE(!row_stats || !(epilogue & OTTER_EPI_RESIDUAL), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_ws: folded LayerNorm takes no residual");
     OTTER_REQUIRE(!workspace || (aligned16(workspace) && workspace_floats > 0), OTTER_ERR_ALIGNMENT, "otter_gemm_ws: workspace must be 16-byte aligned");
     return gemm_impl(dtype, A, lda, W, n_pad, bias, residual, ldr, C, ldc, M, N, K, epilogue, row_stats, col_sum, workspace, workspace_floats, stream);
+}
+
+// ---- allocation-free variant of otter_gemm_ws: the split-K scratch is a static device array ---------------------
+// One copy of the array lives on every GPU the library is loaded on, until the process ends.  Host code must not pass
+// the array's NAME to a kernel (on the host that is a stand-in object, not a device address): the address of the
+// current device's copy is looked up once per device with hipGetSymbolAddress and only that pointer is used.
+constexpr int STATIC_WS_MAX_N = 4096;
+constexpr long STATIC_WS_FLOATS = 8L * 255 * STATIC_WS_MAX_N;      // == otter_gemm_workspace_floats(4096): 33.4 MB
+static __device__ __align__(256) float scratch[STATIC_WS_FLOATS];
+
+static float* static_scratch_of_current_device() {
+    static std::mutex mu;
+    static std::map<int, float*> per_device;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        otter_set_error("otter_gemm_static_ws: no current HIP device");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_device.find(dev);
+    if (it != per_device.end()) return it->second;
+    float* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+        otter_set_error("otter_gemm_static_ws: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+        return nullptr;
+    }
+    per_device[dev] = ptr;
+    return ptr;
+}
+
+extern "C" long otter_gemm_static_ws_max_n(void) { return STATIC_WS_MAX_N; }
+
+extern "C" int otter_gemm_static_ws(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const void* residual,
+                                    long ldr, const float* row_stats, const float* col_sum, void* C, long ldc, int M, int N, int K,
+                                    int epilogue, void* stream) {
+    OTTER_REQUIRE((row_stats == nullptr) == (col_sum == nullptr), OTTER_ERR_INVALID_ARGUMENT, "otter_gemm_static_ws: row_stats and col_sum go together");
+    OTTER_REQUIRE(!row_stats || !(epilogue & OTTER_EPI_RESIDUAL), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_static_ws: folded LayerNorm takes no residual");
+    OTTER_REQUIRE(N <= STATIC_WS_MAX_N, OTTER_ERR_UNSUPPORTED_SHAPE,
+                  "otter_gemm_static_ws: N=%d exceeds the static scratch (N <= %d); use otter_gemm_ws with a caller-provided workspace", N,
+                  STATIC_WS_MAX_N);
+    float* ws = static_scratch_of_current_device();
+    if (!ws) return OTTER_ERR_LAUNCH;
+    // (the split-K pass writes every partial product it later reads, so the scratch needs no clearing between calls)
+    return gemm_impl(dtype, A, lda, W, n_pad, bias, residual, ldr, C, ldc, M, N, K, epilogue, row_stats, col_sum, ws, STATIC_WS_FLOATS, stream);
 }

@@ -66,6 +66,7 @@ template <> struct Half16<__bf16> {
     static __device__ __forceinline__ __bf16 from(float v) { return (__bf16)v; }
     static __device__ __forceinline__ __bf16 from_unit(float v) { return (__bf16)v; }      // v in [0, 1]
     static __device__ __forceinline__ f32x4 mfma32(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32x32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 };
 template <> struct Half16<_Float16> {
@@ -74,6 +75,7 @@ template <> struct Half16<_Float16> {
     static __device__ __forceinline__ _Float16 from(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
     static __device__ __forceinline__ _Float16 from_unit(float v) { return (_Float16)v; }  // v in [0, 1]: no saturation needed
     static __device__ __forceinline__ f32x4 mfma32(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32x32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) {
         union { s16x4 s; f16x4 h; } ua, ub;
         ua.s = a; ub.s = b;

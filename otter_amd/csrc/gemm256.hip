@@ -58,7 +58,10 @@ template <int ACT> __device__ __forceinline__ float act256(float v) {
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false>      // LNF: LayerNorm folded into the epilogue (p.ln_stats)
+// LNF: LayerNorm folded into the epilogue (p.ln_stats).  MF32: the K-loop issues v_mfma_f32_32x32x16 (2 x 1 tiles of
+// 32x32 per quadrant, four 16-element k-sub-steps) instead of v_mfma_f32_16x16x32 (4 x 2 tiles of 16x16, two 32-element
+// k-sub-steps): same LDS image, same fragment bytes, same accumulator count, half as many MFMA instructions.
+template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false, bool MF32 = false>
 __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 frag_t;
@@ -88,12 +91,14 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
             const int lr = (wave * 2 + i) * 8 + (lane >> 3);            // local row inside the half-tile image
             const int c = (lane & 7) ^ ((lr >> 1) & 7);
             const int fi = lr & 15, fnt = (lr >> 4) & 1;
-            const int wcol = (lr >> 5) * 64 + 4 * fi + fnt;
+            // MF32: image row c = lr & 31 of half x is lane c's column in the 32x32 tile; it gets weight row 2c + x, so a
+            // lane's two accumulators of an output row are 2 consecutive columns
+            const int wcol = MF32 ? (lr >> 5) * 64 + 2 * (lr & 31) : (lr >> 5) * 64 + 4 * fi + fnt;
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const int trow = (lr < 64 ? lr : lr + 64) + x * 64;      // A: tile row
                 a_off[x][i] = (unsigned)(m0 + trow) * (unsigned)(p.lda * 2) + c * 16;
-                w_off[x][i] = (unsigned)(n0 + wcol + x * 2) * (unsigned)(p.K * 2) + c * 16;
+                w_off[x][i] = (unsigned)(n0 + wcol + x * (MF32 ? 1 : 2)) * (unsigned)(p.K * 2) + c * 16;
             }
         }
     };
@@ -128,10 +133,15 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     int koff[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) koff[ks] = li * 128 + (((ks * 4 + g) ^ swz) << 4);
+    // MF32: lane (h = lane >> 5, r = lane & 31) reads row r of a 32-row tile, 16-byte chunk 2*ks + h of its 128 bytes
+    int koff32[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff32[ks] = (lane & 31) * 128 + (((ks * 2 + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
     const int a_row0 = wr * 64 * 128;          // this wave's 64 rows inside an A half-tile
     const int b_row0 = wc * 32 * 128;          // this wave's 32 rows inside a B half-tile
 
     f32x4 acc[2][2][4][2];                      // [A half s][B half x][m-tile][n-tile]
+    f32x16 acc32[2][2][2];                      // MF32: [A half s][B half x][32-row m-tile]
     const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
 
     // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The next tile's prologue loads are
@@ -150,6 +160,16 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[s][x][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (MF32) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc32[s][x][mt][j] = 0.f;
+    }
     // first tile: the two youngest half-tiles may stay in flight; later tiles: the epilogue's stores were issued
     // after the prologue loads, so everything is drained
     if (first && nkt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -158,25 +178,45 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     wg_barrier();
 
     frag_t af[4][2], bf[2][2][2];               // A half in use; both B halves of the K-step: [half x][n-tile][k-sub-step]
+    // (MF32 keeps the same register arrays: af[2*mt2 + (ks >> 1)][ks & 1] is fragment (32-row tile mt2, k-sub-step ks),
+    //  bf[x][ks >> 1][ks & 1] fragment (half x, k-sub-step ks))
     auto load_a = [&](int buf, int slot) {
         const char* base = smem + (buf * 4 + slot) * HALF_BYTES + a_row0;
+        if constexpr (MF32) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const frag_t*)(base + mt * 2048 + koff[ks]);
+                for (int ks = 0; ks < 4; ++ks) af[2 * mt + (ks >> 1)][ks & 1] = *(const frag_t*)(base + mt * 4096 + koff32[ks]);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const frag_t*)(base + mt * 2048 + koff[ks]);
+        }
     };
     auto load_b = [&](int buf, int slot, int x) {
         const char* base = smem + (buf * 4 + slot) * HALF_BYTES + b_row0;
+        if constexpr (MF32) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int ks = 0; ks < 4; ++ks) bf[x][ks >> 1][ks & 1] = *(const frag_t*)(base + koff32[ks]);
+        } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bf[x][nt][ks] = *(const frag_t*)(base + nt * 2048 + koff[ks]);
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bf[x][nt][ks] = *(const frag_t*)(base + nt * 2048 + koff[ks]);
+        }
     };
 #define OTTER_QUADRANT(S, X)                                                                              \
+    if constexpr (MF32) {                                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                               \
+                acc32[S][X][mt] = Half16<T>::mfma32x32(af[2 * mt + (ks >> 1)][ks & 1], bf[X][ks >> 1][ks & 1], acc32[S][X][mt]); \
+    } else {                                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                   \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                               \
-                acc[S][X][mt][nt] = Half16<T>::mfma32(af[mt][ks], bf[X][nt][ks], acc[S][X][mt][nt]);
+                acc[S][X][mt][nt] = Half16<T>::mfma32(af[mt][ks], bf[X][nt][ks], acc[S][X][mt][nt]);       \
+    }
 
     // A K-step is two halves, one per A half-tile: load segment (fragment reads + LDS-DMA issues) then MFMA segment (two
     // quadrants = 32 MFMAs per wave), four workgroup barriers per K-step.  Both B halves are read in the first half
@@ -238,6 +278,57 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
         set_tile(tile);
         issue_prologue();
     }
+    if constexpr (MF32) {
+        // lane (h, c): rows 32mt + 8(j >> 2) + 4h + (j & 3) of each 64-row half, columns 2c + 0..1 of the wave's 64
+        const int h = lane >> 5, c = lane & 31;
+        const int n = cn0 + wc * 64 + 2 * c;
+        if (n < p.N) {
+            f32x2 bv = {0.f, 0.f}, cs = bv;
+            if (p.bias) bv = *(const f32x2*)(p.bias + n);
+            if (LNF) cs = *(const f32x2*)(p.ln_colsum + n);
+            typedef __attribute__((ext_vector_type(2))) T h2;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x2 rf[RES && OUT_F32 ? 16 : 1];
+                    h2 rh[RES && !OUT_F32 ? 16 : 1];
+                    f32x2 st[LNF ? 16 : 1];
+                    const int mbase = cm0 + wr * 128 + s * 64 + mt * 32 + 4 * h;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int m = mbase + 8 * (j >> 2) + (j & 3);
+                        if (LNF) st[j] = *(const f32x2*)(p.ln_stats + 2 * (long)m);
+                        if (RES) {
+                            const long off = (long)m * p.ldr + n;
+                            if constexpr (OUT_F32) rf[j] = *(const f32x2*)((const float*)p.residual + off);
+                            else rh[j] = *(const h2*)((const T*)p.residual + off);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int m = mbase + 8 * (j >> 2) + (j & 3);
+                        f32x2 v = (f32x2){acc32[s][0][mt][j], acc32[s][1][mt][j]};
+                        if (LNF) v = (v - st[j][0] * cs) * st[j][1];
+                        v += bv;
+                        v[0] = act256<ACT>(v[0]);
+                        v[1] = act256<ACT>(v[1]);
+                        if (RES) {
+                            if constexpr (OUT_F32) v += rf[j];
+                            else { v[0] += (float)rh[j][0]; v[1] += (float)rh[j][1]; }
+                        }
+                        if constexpr (OUT_F32) {
+                            *(f32x2*)((float*)p.C + (long)m * p.ldc + n) = v;
+                        } else {
+                            h2 o;
+                            o[0] = Half16<T>::from(v[0]);
+                            o[1] = Half16<T>::from(v[1]);
+                            *(h2*)((T*)p.C + (long)m * p.ldc + n) = o;
+                        }
+                    }
+                }
+        }
+    } else
     // lane (g, li): rows 16mt + 4g + r, columns 4li + 0..3 of the wave's 64
     {
         const int n = cn0 + wc * 64 + 4 * li;
@@ -309,9 +400,9 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
 #undef OTTER_QUADRANT
 }
 
-template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false>
+template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false, bool MF32 = false>
 int launch256(const Gemm256Args& a, hipStream_t s) {
-    auto kern = gemm_256x256<T, ACT, OUT_F32, RES, LNF>;
+    auto kern = gemm_256x256<T, ACT, OUT_F32, RES, LNF, MF32>;
     if (int rc = otter_reserve_lds((const void*)kern, LDS_BYTES, "otter_gemm (256x256)")) return rc;
     const int n_cu = otter_cu_count("otter_gemm (256x256)");
     if (n_cu <= 0) return OTTER_ERR_LAUNCH;
@@ -322,7 +413,17 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
 }
 
 template <typename T>
-int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, hipStream_t s) {
+int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, bool mf32, hipStream_t s) {
+    if (mf32) {         // measurement variant: 16-bit output, the three epilogues of a CLIP block
+        if (out_f32) { otter_set_error("otter_gemm (256x256, 32x32x16): 16-bit output only"); return OTTER_ERR_UNSUPPORTED_SHAPE; }
+        if (res) return launch256<T, ACT_NONE, false, true, false, true>(a, s);
+        if (a.ln_stats) {
+            if (act == OTTER_EPI_ACT_NONE) return launch256<T, ACT_NONE, false, false, true, true>(a, s);
+            if (act == OTTER_EPI_ACT_QUICKGELU) return launch256<T, ACT_QUICKGELU, false, false, true, true>(a, s);
+        } else if (act == OTTER_EPI_ACT_NONE) return launch256<T, ACT_NONE, false, false, false, true>(a, s);
+        otter_set_error("otter_gemm (256x256, 32x32x16): epilogue not instantiated");
+        return OTTER_ERR_UNSUPPORTED_SHAPE;
+    }
     if (res) return out_f32 ? launch256<T, ACT_NONE, true, true>(a, s) : launch256<T, ACT_NONE, false, true>(a, s);
     if (a.ln_stats && !out_f32) {
         switch (act) {
@@ -356,11 +457,11 @@ bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K,
 
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                          void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
-                         const float* ln_colsum, hipStream_t s) {
+                         const float* ln_colsum, bool mf32, hipStream_t s) {
     if (M <= 0 || M % TM != 0) {                     // whole 256-row tiles only: the caller sends the remainder elsewhere
         otter_set_error("otter_gemm (256x256): M=%d is not a positive multiple of %d", M, TM);
         return OTTER_ERR_UNSUPPORTED_SHAPE;
     }
     Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, (N + TN - 1) / TN, ln_stats, ln_colsum};
-    return dtype == DT_BF16 ? dispatch256<__bf16>(a, act, out_f32, res, s) : dispatch256<_Float16>(a, act, out_f32, res, s);
+    return dtype == DT_BF16 ? dispatch256<__bf16>(a, act, out_f32, res, mf32, s) : dispatch256<_Float16>(a, act, out_f32, res, mf32, s);
 }

@@ -47,14 +47,17 @@ class _EncodeGraph:
         d = dev.device
         self.images, self.text, self.proprio = images.to(d).clone(), text_feats.to(d).clone(), proprio.to(d).clone()
         self.mask = None if text_mask is None else text_mask.to(d).clone()
+        # the graph's own split-K scratch: its address is baked into the captured launches, and another graph may be
+        # replayed on another stream at the same time
+        self.ws = ops.new_gemm_workspace(d)
         cur = torch.cuda.current_stream(d)
         side = torch.cuda.Stream(device=d)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):              # once eagerly: LDS opt-ins, scratch buffers and allocator pools exist before capture
+        with torch.cuda.stream(side), ops.gemm_workspace(self.ws):     # once eagerly: LDS opt-ins and allocator pools exist before capture
             dev.encode(self.images, self.text, self.proprio, 1, self.mask)
         cur.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), ops.gemm_workspace(self.ws):
             self.out = dev.encode(self.images, self.text, self.proprio, 1, self.mask)
 
     def __call__(self, images: Tensor, text_feats: Tensor, proprio: Tensor, text_mask: Optional[Tensor]) -> Tensor:

@@ -6,14 +6,16 @@ passes raw pointers to ``libotter_hip.so``.  No function here computes anything 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
+import threading
 from typing import Optional, Sequence
 
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, DT_BF16, DT_F16, DT_F32, OUT_F32, RESIDUAL, TILE_128,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, DT_BF16, DT_F16, DT_F32, MFMA_32X32, OUT_F32, RESIDUAL, TILE_128,  # noqa: F401
                    OtterHipError, ReadoutBlock)
 
 Tensor = torch.Tensor
@@ -80,15 +82,47 @@ def pack_weight(w: Tensor, dtype=torch.bfloat16, device=None) -> Tensor:
 
 _GEMM_WS = {}
 _SPLIT_K = os.environ.get("OTTER_SPLIT_K", "1") != "0"       # tuning knob: 0 = never take the split-K path
+MFMA_32 = os.environ.get("OTTER_GEMM_MFMA32", "0") == "1"     # measurement knob: 32x32x16 MFMAs in the 256x256 kernel where instantiated
 
 
-def _gemm_workspace(device, n: int) -> Tensor:
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+_GEMM_WS_GUARD = threading.Lock()
+_WS_LOCAL = threading.local()
+
+
+def new_gemm_workspace(device, n: int = 4096) -> Tensor:
+    """A split-K scratch buffer large enough for products with up to ``n`` output columns."""
+    return torch.empty(_lib.load().otter_gemm_workspace_floats(round_up(n, 64)), dtype=torch.float32, device=device)
+
+
+@contextlib.contextmanager
+def gemm_workspace(ws: Tensor):
+    """Every :func:`gemm` this thread issues inside the block uses ``ws`` as its split-K scratch.  A captured HIP graph bakes
+    the scratch address in, whatever stream it is later replayed on, so every graph owns a buffer of its own: two graphs
+    replayed at the same time on different streams must not share partial products."""
+    prev = getattr(_WS_LOCAL, "ws", None)
+    _WS_LOCAL.ws = ws
+    try:
+        yield ws
+    finally:
+        _WS_LOCAL.ws = prev
+
+
+def _gemm_workspace(device, n: int):
+    """-> (scratch, lock or None).  Default: one buffer per (device, current stream) and a lock that makes the
+    partial-product launch and the reduce launch of one call adjacent on that stream (ctypes releases the GIL during the
+    call; without the lock two threads on one stream could interleave as A.partial, B.partial, A.reduce)."""
     need = _lib.load().otter_gemm_workspace_floats(round_up(n, 64))
-    ws = _GEMM_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _GEMM_WS[key] = torch.empty(need, dtype=torch.float32, device=device)
-    return ws
+    own = getattr(_WS_LOCAL, "ws", None)
+    if own is not None and own.device == device:
+        if own.numel() < need:
+            raise ValueError(f"gemm: the scoped workspace holds {own.numel()} floats, N={n} needs {need}")
+        return own, None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    with _GEMM_WS_GUARD:
+        entry = _GEMM_WS.get(key)
+        if entry is None or entry[0].numel() < need:
+            entry = _GEMM_WS[key] = (torch.empty(need, dtype=torch.float32, device=device), entry[1] if entry else threading.Lock())
+    return entry
 
 
 def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
@@ -116,6 +150,8 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         raise ValueError(f"gemm.residual: {residual.dtype}, expected float32 or {a.dtype}")
     f32_out = out_f32 or (residual is not None and residual.dtype == torch.float32) or a.dtype == torch.float32
     epi = act | (OUT_F32 if f32_out else 0) | (RESIDUAL if residual is not None else 0) | (TILE_128 if force_tile_128 else 0)
+    if MFMA_32 and not f32_out and act in (ACT_NONE, ACT_QUICKGELU) and (act == ACT_NONE or ln_stats is not None):
+        epi |= MFMA_32X32
     odt = torch.float32 if f32_out else a.dtype
     if out is None:
         out = torch.empty(m, n, dtype=odt, device=a.device)
@@ -140,9 +176,11 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         if tuple(ln_stats.shape) != (m, 2) or ln_colsum.numel() < n or not ln_stats.is_contiguous():
             raise ValueError("gemm: ln_stats must be (M, 2) contiguous and ln_colsum at least N long")
     # scratch for the split-K pass over the remainder rows of a big 16-bit problem (one buffer per device and stream)
-    ws = _gemm_workspace(a.device, n) if (split_k and _SPLIT_K and (m < 256 if a.dtype == torch.float32 else (m % 256 != 0 or m < 1024))) else None
-    _lib.call("otter_gemm_ws", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
-              _ptr(ln_stats), _ptr(ln_colsum), _ptr(out), ldc, m, n, k, epi, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+    ws, lock = (_gemm_workspace(a.device, n) if (split_k and _SPLIT_K and (m < 256 if a.dtype == torch.float32 else (m % 256 != 0 or m < 1024)))
+                else (None, None))
+    with lock if lock is not None else contextlib.nullcontext():
+        _lib.call("otter_gemm_ws", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(residual), ldr,
+                  _ptr(ln_stats), _ptr(ln_colsum), _ptr(out), ldc, m, n, k, epi, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     return out
 
 

@@ -74,6 +74,8 @@ class OTTER(nn.Module):
         self._tail = None
         self._rollout: Optional[BatchedRollout] = None
         self._param_groups = None
+        self._carry_window = None
+        self.check_weights_by_value = False       # opt-in: a value checksum of the weights in the staleness key (one device sync per forward)
         self.cache_size = 0
 
     # ------------------------------------------------------------------ device state
@@ -93,13 +95,37 @@ class OTTER(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _weights_key(self, trainable: bool):
-        """Changes whenever a parameter of the group is written in place (optimizer step, ``copy_``); moves and
-        ``load_state_dict`` drop the packed copies directly.  Called on every forward: the parameter lists are cached (the
-        module tree is fixed after construction) so that the check costs one attribute read per tensor."""
+        """Changes whenever a tensor of the group is written in place through the tensor itself (optimizer step, ``p.copy_``,
+        ``p.mul_``: the version counter) or re-pointed (``p.data = other``: the storage address); moves and
+        ``load_state_dict`` drop the packed copies directly.  Writes THROUGH ``p.data`` / ``p.detach()`` (``p.data.copy_()``,
+        an EMA ``p.data.mul_()``) or through raw pointers change neither: call :meth:`invalidate_device_weights` after them,
+        or set ``check_weights_by_value`` to have every forward compare a checksum of the values.  Buffers that the device
+        model packs (``pe.pe``, ``visual_extraction.*.pos_emb``) are part of the trainable group's key.  Called on every
+        forward: the tensor lists are cached (the module tree is fixed after construction) so that the check costs two
+        attribute reads per tensor."""
         if self._param_groups is None:
             named = list(self.named_parameters())
-            self._param_groups = ([p for n, p in named if n.startswith("clip_model.")], [p for n, p in named if not n.startswith("clip_model.")])
-        return tuple(p._version for p in self._param_groups[1 if trainable else 0])
+            self._param_groups = ([p for n, p in named if n.startswith("clip_model.")],
+                                  [p for n, p in named if not n.startswith("clip_model.")] + [b for _, b in self.named_buffers()])
+        group = self._param_groups[1 if trainable else 0]
+        key = tuple(p._version for p in group) + tuple(p.data_ptr() for p in group)
+        if self.check_weights_by_value:
+            key += (float(torch.stack([p.detach().double().sum() for p in group]).sum().item()),)
+        return key
+
+    def invalidate_device_weights(self, towers: bool = True, keep_history: bool = True) -> None:
+        """Drop the packed device copies of the weights (and the captured graphs built on them): the next forward repacks
+        from the module's tensors.  For writers the automatic check cannot see: in-place writes through ``p.data`` /
+        ``p.detach()``, raw-pointer kernels (the device AdamW of :class:`otter_amd.trainer.Trainer`).  ``towers=False``
+        keeps the packed CLIP towers (0.86 GB; only the trainable modules changed).  ``keep_history`` carries the running
+        episode's window of policy inputs over to the new weights."""
+        self._carry_window = self._window_snapshot() if keep_history else None
+        self._dev = None
+        if towers:
+            self._clip_dev = None
+        if self._tail is not None:
+            self._tail._dims_key = None                # packed buffer tables of the training tail
+        self._rollout = None
 
     def _device(self) -> torch.device:
         device = self.input_projection.weight.device
@@ -126,6 +152,8 @@ class OTTER(nn.Module):
         clip = self.clip_device()
         key = self._weights_key(True)
         if self._dev is None or self._dev_key != key:
+            if self._rollout is not None and self._carry_window is None:
+                self._carry_window = self._window_snapshot()      # a weight changed mid-episode: the history survives the repack
             self._dev = OtterDevice(
                 dict(self.state_dict()), self.clip_arch, first_k=self.first_k_tokens, pooling_heads=self.pooling_heads,
                 transformer_heads=self.transformer_heads, num_cameras=len(self.camera_keys), seq_length=self.seq_length,
@@ -136,24 +164,45 @@ class OTTER(nn.Module):
         return self._dev
 
     # ------------------------------------------------------------------ rollout cache (otter.py:153-175)
+    def _window_snapshot(self) -> Optional[Tensor]:
+        if self._rollout is None or self.cache_size == 0:
+            return None
+        return self._rollout.window[:, : self.cache_size].clone()
+
     def _get_rollout(self) -> BatchedRollout:
         dev = self.device_model()
         if self._rollout is None:
             self._rollout = BatchedRollout(dev, 1)
             self.cache_size = 0
+            carried, self._carry_window = self._carry_window, None
+            if carried is not None:
+                # The policy inputs of the running episode are kept; they were produced by the OLD encoder weights, as
+                # they would be in the reference (its cache holds inputs, otter.py:158-175).  K/V rows are recomputed.
+                self.update_cache(carried)
         return self._rollout
 
     def reset_cache(self):
         """Reset the transformer input cache."""
+        self._carry_window = None
         if self._rollout is not None:
             self._rollout.reset()
         self.cache_size = 0
 
     @property
     def cached_transformer_input(self) -> Optional[Tensor]:
+        """(1, cache_size, transformer_dim) policy inputs of the running episode, or None (``otter.py:149-151``)."""
         if self._rollout is None or self.cache_size == 0:
-            return None
+            return self._carry_window
         return self._rollout.window[:, : self.cache_size]
+
+    @cached_transformer_input.setter
+    def cached_transformer_input(self, value: Optional[Tensor]) -> None:
+        # the reference exposes a plain attribute: ``= None`` clears the cache, a tensor replaces its contents
+        self.reset_cache()
+        if value is not None:
+            if value.dim() != 3 or value.shape[0] != 1:
+                raise ValueError(f"cached_transformer_input must be (1, T, dim), got {tuple(value.shape)}")
+            self.update_cache(value[:, -self.seq_length:])
 
     # ------------------------------------------------------------------ helpers
     def _images_nchw(self, images: Tensor) -> Tuple[Tensor, int, int]:
@@ -243,7 +292,15 @@ class OTTER(nn.Module):
         if isinstance(text, list):
             text = tokenize(text)
         text_mask = create_text_mask(text, self.sot_token, self.eot_token, self.first_k_tokens) if self.pool_true_text else None
-        # uint8 images are normalised on the device inside the patch-extraction kernel (vision_tf.py:35-45)
+        # Every non-float dtype is normalised (otter.py:367-368).  uint8 images are normalised on the device inside the
+        # patch-extraction kernel (vision_tf.py:35-45); other integer types hold pixel values too and take the same
+        # route when they fit a byte, else the elementwise transform itself (/255, mean, std) on their device.
+        if not torch.is_floating_point(images) and images.dtype != torch.uint8:
+            if images.numel() == 0 or (int(images.min()) >= 0 and int(images.max()) <= 255):
+                images = images.to(torch.uint8)
+            else:
+                from .vision_tf import clip_transform_host
+                images = clip_transform_host(images)
         if gt_actions is None:
             return self.forward_actions(images, text, proprio, text_mask)
         return self.loss(images, text, proprio, gt_actions, text_mask)
@@ -258,8 +315,8 @@ class OTTER(nn.Module):
         device = self._device()
         ids = text.detach().to("cpu", torch.int32).view(-1, text.shape[-1])
         imgs = images.to(device)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in tail.params.values()):
-            names = list(tail.params)
+        names = tail.trainable_names()                       # frozen parameters take part in the forward pass only
+        if torch.is_grad_enabled() and names:
             return TailLoss.apply(tail, imgs, ids, proprio, gt_actions, text_mask, names, *[tail.params[n] for n in names])
         with torch.no_grad():
             return tail.forward_backward(imgs, ids, proprio, gt_actions, text_mask, None).view(())

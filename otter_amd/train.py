@@ -96,8 +96,14 @@ def layernorm(tape: Tape, x: Var, gamma: Var, beta: Var, out: Optional[Var] = No
     def bwd():
         if out.g is None:
             return
-        ops.layernorm_bwd(x.t, gamma.t, out.g, x.grad() if x.needs_grad else None,
-                          gamma.grad() if gamma.needs_grad else None, beta.grad() if gamma.needs_grad else None)
+        dgamma = gamma.grad() if gamma.needs_grad else None
+        dbeta = beta.grad() if beta.needs_grad else None
+        if (dgamma is None) != (dbeta is None):       # the kernel produces both or neither: the frozen one gets a throw-away buffer
+            dgamma = dgamma if dgamma is not None else torch.zeros_like(gamma.t)
+            dbeta = dbeta if dbeta is not None else torch.zeros_like(beta.t)
+        if not x.needs_grad and dgamma is None:
+            return
+        ops.layernorm_bwd(x.t, gamma.t, out.g, x.grad() if x.needs_grad else None, dgamma, dbeta)
     tape.record(bwd)
     return out
 
@@ -148,8 +154,13 @@ class TrainableTail:
 
     def __init__(self, model):
         self.model = model
-        self.params: Dict[str, torch.nn.Parameter] = {n: p for n, p in model.named_parameters() if p.requires_grad}
+        # every parameter outside the frozen towers, trainable or not: a frozen one (action-head-only fine-tuning, a model
+        # loaded by OtterInference) takes part in the forward pass and simply gets no gradient buffer
+        self.params: Dict[str, torch.nn.Parameter] = {n: p for n, p in model.named_parameters() if not n.startswith("clip_model.")}
         self.buffers = dict(model.named_buffers())
+
+    def trainable_names(self) -> List[str]:
+        return [n for n, p in self.params.items() if p.requires_grad]
 
     def _dims(self, device, clip_dtype):
         """Sizes and constant tables (cached): pooled widths, transposed pos_emb tables, the window positional table."""
@@ -170,22 +181,23 @@ class TrainableTail:
 
     # -- parameter access ------------------------------------------------------------------------------------------
     def _var(self, grads: Dict[str, Tensor], name: str, shape2d: Optional[Tuple[int, int]] = None) -> Var:
-        p = self.params[name]
-        g = grads[name]
-        t = p.detach()
+        """The parameter as a tape variable; it collects a gradient iff ``grads`` holds a buffer for it."""
+        t = self.params[name].detach()
+        g = grads.get(name)
         if shape2d is not None:
-            return Var(t.view(*shape2d), True, g.view(*shape2d))
-        return Var(t, True, g)
+            t = t.view(*shape2d)
+            g = None if g is None else g.view(*shape2d)
+        return Var(t, g is not None, g)
 
     def _slice(self, v: Var, lo: int, hi: int) -> Var:
-        return Var(v.t[lo:hi], True, v.g[lo:hi])
+        return Var(v.t[lo:hi], v.needs_grad, None if v.g is None else v.g[lo:hi])
 
     # -- modules ------------------------------------------------------------------------------------------------------
     def _pooling(self, tape: Tape, G, prefix: str, x: Var, n_obs: int, nk: int, heads: int, mask: Optional[Tensor], out: Var) -> None:
         """AttentionPooling (transformer.py:162-232) on x (n_obs*nk, D_in) -> out (n_obs, readouts*d) view."""
         query = self._var(G, prefix + "query")
         _, r, d = query.t.shape
-        q = Var(query.t.view(r, d), True, query.g.view(r, d))           # shared by every observation until the first residual
+        q = Var(query.t.view(r, d), query.needs_grad, None if query.g is None else query.g.view(r, d))   # shared by every observation until the first residual
         shared = True
         i = 0
         while (prefix + f"blocks.{i}.q_layer_norm.weight") in self.params:
@@ -233,7 +245,7 @@ class TrainableTail:
         m = b * t
         k = model.first_k_tokens
         want = grads is not None
-        G = grads if want else {n: p.detach() for n, p in self.params.items()}      # placeholder buffers when only the loss is needed
+        G = grads if want else {}                                                   # no buffers: nothing collects a gradient
         tape = Tape()
         device = clip.device
 
@@ -317,7 +329,8 @@ class TrainableTail:
         tg = torch.zeros(cams, dtype=torch.float32, device=device)
         ops.col_sum(part, tg, accumulate=False)
         for c in range(cams):
-            ops.add_inplace(grads[f"visual_extraction.{c}.temperature"].view(1), tg[c:c + 1])
+            if f"visual_extraction.{c}.temperature" in grads:
+                ops.add_inplace(grads[f"visual_extraction.{c}.temperature"].view(1), tg[c:c + 1])
         return loss
 
 

@@ -135,7 +135,7 @@ class Trainer:
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.tail = TrainableTail(model)
-        self.grads = {n: self.flat_g[where[id(p)][0]:where[id(p)][1]].view(p.shape) for n, p in self.tail.params.items()}
+        self.grads = {n: self.flat_g[where[id(p)][0]:where[id(p)][1]].view(p.shape) for n, p in self.tail.params.items() if id(p) in where}
         self.base_lr, self.betas, self.eps = lr, betas, eps
         self.warmup_steps, self.num_steps, self.accum_iter = warmup_steps, num_steps, max(1, accum_iter)
         self.scaler = LossScale(enabled=loss_scaling)
@@ -178,8 +178,7 @@ class Trainer:
             out["grad_norm"] = float("inf") if found_inf else math.sqrt(sumsq) * inv
             out["skipped"] = found_inf
             self.scaler.update(found_inf)
-            model._dev = None                                     # packed inference weights are stale now
-            model._rollout = None
+            model.invalidate_device_weights(towers=False)         # AdamW wrote the flat buffer through raw pointers
         out["loss"] = float(loss.item())
         self.iteration += 1
         return out

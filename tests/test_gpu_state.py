@@ -1,0 +1,172 @@
+"""Device-state bookkeeping of the OTTER object on the GPU: when packed weights are rebuilt, what happens to a running
+episode when they are, the reference's plain-attribute cache semantics, integer image dtypes, and captured encoder graphs
+replayed at the same time on two streams."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+from oracle import otter_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from otter_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _model(mc, sc, seed, dev):
+    from otter_amd.otter import OTTER
+    from otter_amd.params import otter_specs, random_state_dict
+    sd = random_state_dict(otter_specs(mc, sc), seed=seed)
+    model = OTTER(mc, sc)
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev).eval(), sd
+
+
+def _obs(case, dev, step=0):
+    r_images, r_text, r_proprio = GI.rollout_inputs(case)
+    return r_images[step].to(dev), r_text, r_proprio[step].to(dev)
+
+
+def test_weight_writes_reach_the_device_copies(dev):
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    img, text, prop = _obs(case, dev)
+
+    def first_action():
+        model.reset_cache()
+        return model.forward_inference(img, text, prop).cpu()
+
+    base = first_action()
+    bias = model.action_head.mlp[2].bias
+    # (1) a write through the tensor itself bumps its version counter: seen automatically
+    with torch.no_grad():
+        bias.add_(0.25)
+    torch.testing.assert_close(first_action(), base + 0.25, rtol=0, atol=1e-5)
+    # (2) re-pointing .data (the reference does this to its CLIP parameters, otter/policy/otter.py:80): seen automatically
+    bias.data = bias.data + 0.25
+    torch.testing.assert_close(first_action(), base + 0.5, rtol=0, atol=1e-5)
+    # (3) an in-place write THROUGH .data changes neither version nor address.  (Tensors the device model uses in place --
+    #     fp32 biases and LayerNorm vectors -- show it anyway; a packed matrix does not: the explicit call is needed.)
+    weight = model.action_head.mlp[2].weight
+    before = first_action()
+    weight.data.mul_(1.5)
+    assert torch.equal(first_action(), before)                  # stale, as documented
+    model.invalidate_device_weights()
+    after = first_action()
+    assert (after - before).abs().max().item() > 1e-3
+    # (4) ... or the opt-in value checksum
+    model.check_weights_by_value = True
+    first_action()
+    weight.data.mul_(1.0 / 1.5)
+    torch.testing.assert_close(first_action(), before, rtol=0, atol=1e-5)
+    model.check_weights_by_value = False
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length)
+    now = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = R.Rollout(now, dims).step(R.clip_transform(img.cpu()), text, prop.cpu())
+    assert (first_action() - ref).abs().max().item() <= 1e-3
+    # (5) buffers that the device model packs are part of the key too
+    with torch.no_grad():
+        model.pe.pe.add_(0.1)
+    assert (first_action() - before).abs().max().item() > 1e-4
+
+
+def test_history_survives_a_weight_change_and_cache_attribute_assignment(dev):
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    r_images, r_text, r_proprio = GI.rollout_inputs(case)
+    model.reset_cache()
+    for t in range(2):
+        model.forward_inference(r_images[t].to(dev), r_text, r_proprio[t].to(dev))
+    before = model.cached_transformer_input.clone()
+    assert before.shape[:2] == (1, 2)
+    with torch.no_grad():
+        model.action_head.mlp[2].bias.add_(1.0)              # e.g. an optimizer step between two calls of one episode
+    a2 = model.forward_inference(r_images[2].to(dev), r_text, r_proprio[2].to(dev)).cpu()
+    assert model.cache_size == 3                                # the episode went on: history was carried over
+    torch.testing.assert_close(model.cached_transformer_input[:, :2], before, rtol=0, atol=0)
+    # the same three steps on the oracle with the changed head
+    sd2 = dict(sd)
+    sd2["action_head.mlp.2.bias"] = sd["action_head.mlp.2.bias"] + 1.0
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length)
+    ro = R.Rollout(sd2, dims)
+    for t in range(3):
+        ref = ro.step(R.clip_transform(r_images[t]), r_text, r_proprio[t])
+    assert (a2 - ref).abs().max().item() <= 1e-3
+
+    # the reference's cache is a plain attribute (otter/policy/otter.py:149-151): assignment works
+    window = model.cached_transformer_input.clone()
+    model.cached_transformer_input = None
+    assert model.cache_size == 0 and model.cached_transformer_input is None
+    model.cached_transformer_input = window
+    assert model.cache_size == 3
+    torch.testing.assert_close(model.cached_transformer_input, window, rtol=0, atol=0)
+    a3 = model.forward_inference(r_images[3].to(dev), r_text, r_proprio[3].to(dev)).cpu()
+    ref3 = ro.step(R.clip_transform(r_images[3]), r_text, r_proprio[3])
+    assert (a3 - ref3).abs().max().item() <= 1e-3
+    with pytest.raises(ValueError):
+        model.cached_transformer_input = window[0]
+
+
+@pytest.mark.parametrize("dtype", [torch.int16, torch.int32, torch.int64])
+def test_every_integer_image_dtype_is_normalised(dev, dtype):
+    """otter/policy/otter.py:367-368 normalises every non-float image tensor, not only uint8."""
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    images, text, proprio, gt = GI.e2e_inputs(case)
+    assert images.dtype == torch.uint8
+    want = model(images.to(dev), text, proprio.to(dev)).cpu()
+    got = model(images.to(dtype).to(dev), text, proprio.to(dev)).cpu()
+    assert torch.equal(got, want)
+    # values outside a byte cannot ride the uint8 route: the elementwise transform itself, against the oracle's
+    big = images.to(dtype) * 2
+    got = model(big.to(dev), text, proprio.to(dev)).cpu()
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length)
+    with torch.no_grad():
+        ref = R.forward(R.clip_transform(big), text, proprio, sd, dims)
+    assert (got - ref).abs().max().item() <= 1e-3
+
+
+def test_two_encoder_graphs_replayed_on_two_streams(dev):
+    """Each captured encoder graph owns its split-K scratch: two rollouts stepping at the same time on different streams
+    give what they give one after the other."""
+    from otter_amd import engine
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, _ = _model(mc, sc, case["seed"], dev)
+    dm = model.device_model()
+    cams, res = len(model.camera_keys), sc.image_size
+    g = torch.Generator().manual_seed(3)
+    steps = 12
+    inputs = [[(torch.randint(0, 256, (cams, 3, res, res), dtype=torch.uint8, generator=g).to(dev),
+                torch.randn(1, mc.first_k_tokens, dm.clip.embed, generator=g).to(dev),
+                torch.randn(1, mc.proprio_input_dim, generator=g).to(dev)) for _ in range(steps)] for _ in range(2)]
+    serial = []
+    for e in range(2):
+        ro = engine.BatchedRollout(dm, 1)
+        serial.append([ro.step(*inputs[e][t]).clone() for t in range(steps)])
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    ros = [engine.BatchedRollout(dm, 1) for _ in range(2)]
+    outs = [[], []]
+    for t in range(steps):
+        for e in range(2):
+            with torch.cuda.stream(streams[e]):
+                outs[e].append(ros[e].step(*inputs[e][t]).clone())
+    torch.cuda.synchronize()
+    assert ros[0]._graph is not None and ros[0]._graph.ws.data_ptr() != ros[1]._graph.ws.data_ptr()
+    for e in range(2):
+        for t in range(steps):
+            assert torch.equal(outs[e][t], serial[e][t]), (e, t)

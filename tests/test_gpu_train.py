@@ -242,6 +242,35 @@ def test_tail_gradients_match_reference_and_oracle(dev, golden, case):
     print(f"{n}: {checked} trainable tensors, worst relative gradient error {worst:.2e}")
 
 
+def test_partly_frozen_model_trains_and_fully_frozen_model_evaluates(dev):
+    """Action-head-only fine-tuning (every other parameter frozen) and the loss of a fully frozen model (what
+    OtterInference loads): the reference gets both from autograd."""
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    images, text, proprio, gt = GI.e2e_inputs(case)
+    full, _ = _model(mc, sc, case["seed"], dev)
+    full.train()
+    loss_full = full(images.to(dev), text, proprio.to(dev), gt.to(dev))
+    loss_full.backward()
+    part, _ = _model(mc, sc, case["seed"], dev)
+    part.train()
+    for n, p in part.named_parameters():
+        p.requires_grad_(n.startswith("action_head.") or n == "policy.layers.0.pre_ln.bias")    # a lone LayerNorm bias too
+    loss = part(images.to(dev), text, proprio.to(dev), gt.to(dev))
+    assert loss.requires_grad and abs(loss.item() - loss_full.item()) <= 1e-6
+    loss.backward()
+    fp, pp = dict(full.named_parameters()), dict(part.named_parameters())
+    for n, p in pp.items():
+        if p.requires_grad:
+            torch.testing.assert_close(p.grad, fp[n].grad, rtol=1e-4, atol=1e-7)
+        else:
+            assert p.grad is None
+    for p in part.parameters():
+        p.requires_grad_(False)
+    frozen = part(images.to(dev), text, proprio.to(dev), gt.to(dev))
+    assert not frozen.requires_grad and abs(frozen.item() - loss_full.item()) <= 1e-6
+
+
 def test_loss_scaling_and_accumulation(dev):
     case = GI.E2E_CASES[0]
     mc, sc = GI.e2e_configs(case)

@@ -28,6 +28,40 @@ PER_GPU_EPISODES = 64
 EPISODE_LEN = 24            # 12 cached steps + 12 sliding-window steps, then reset
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X
 PEAK_HBM_GBS = 8000.0       # HBM3E peak
+POOL_UNIT_BYTES = 256 * 768 * 2 + 15 * 768 * 2 + 15 * 768 * 2     # 439,296: 16-bit patches in + text in + out per (obs, camera)
+GEMM_SOURCES = ("otter_amd/csrc/gemm256.hip", "otter_amd/csrc/gemm.hip", "otter_amd/csrc/common.hpp")
+
+
+def kernel_sources_sha256() -> str:
+    """Fingerprint of the GEMM kernel sources: a counter file under profiles/ is only quoted while it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in GEMM_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pmc_counters_of_this_kernel():
+    """(traffic bytes per launch, MFMA-busy fraction, source tag) from the newest profiles/*_gemm_traffic.json -- the PMC
+    passes of this same command, collected by scripts/collect_profiles.sh -- or (None, None, reason) when that file was
+    made from other kernel sources than the ones in this tree (the counters cannot be collected inside an un-profiled run)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))
+    if not files:
+        return None, None, "no profiles/*_gemm_traffic.json"
+    path = files[-1]
+    try:
+        with open(path) as fh:
+            pmc = json.load(fh)
+        if pmc.get("kernel_sources_sha256") != kernel_sources_sha256():
+            print(f"bench: {os.path.basename(path)} was collected from other GEMM sources than this tree's: roofline.traffic left null "
+                  "(re-run scripts/collect_profiles.sh)", file=sys.stderr)
+            return None, None, f"profiles/{os.path.basename(path)} is stale (kernel sources changed since it was collected)"
+        return pmc["traffic_bytes_per_launch"], pmc.get("mfma_busy_fraction_of_simd_cycles"), \
+            f"profiles/{os.path.basename(path)} (rocprofv3 --pmc passes of this command; kernel sources sha256 {pmc['kernel_sources_sha256'][:12]})"
+    except (OSError, KeyError, ValueError) as exc:
+        return None, None, f"unreadable counter file: {exc}"
 
 
 def build_model(device, seed=0, clip_dtype=torch.float16):
@@ -80,6 +114,49 @@ class Workload:
         out = self.rollout.step(self.images[i], self.text, self.proprio[i])
         self.t += 1
         return out
+
+
+def measure_with_h2d(work: "Workload", steps: int) -> float:
+    """Seconds for `steps` steps when the uint8 frames and the proprioception start in PINNED HOST memory every step (what
+    a camera driver hands over): uploads run on a copy stream one step ahead of the compute stream, two device buffers."""
+    dev = work.images[0].device
+    host_img = [t.cpu().pin_memory() for t in work.images]
+    host_prop = [t.cpu().pin_memory() for t in work.proprio]
+    d_img = [torch.empty_like(work.images[0]) for _ in range(2)]
+    d_prop = [torch.empty_like(work.proprio[0]) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+    main = torch.cuda.current_stream(dev)
+
+    def upload(t):
+        b, i = t % 2, t % work.n_sets
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[b])              # the step that read this buffer two steps ago is done
+            d_img[b].copy_(host_img[i], non_blocking=True)
+            d_prop[b].copy_(host_prop[i], non_blocking=True)
+            ready[b].record(copy_stream)
+
+    for b in range(2):
+        consumed[b].record(main)
+    work.t = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    upload(0)
+    for t in range(steps):
+        if t + 1 < steps:
+            upload(t + 1)
+        b = t % 2
+        main.wait_event(ready[b])
+        if work.t % EPISODE_LEN == 0:
+            work.rollout.reset()
+            work.dev.clip._text_cache.clear()
+            work.text = work.dev.clip.text_tokens_cached(work.tokens)
+        work.rollout.step(d_img[b], work.text, d_prop[b])
+        consumed[b].record(main)
+        work.t += 1
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
 class TrainWorkload:
@@ -153,12 +230,12 @@ def measure_kernels(work, steps: int):
         return out
 
     def tave_bytes(a, k, out):
-        # compulsory traffic per (observation, camera): patches in (bf16) + text in + out (fp32 here)
+        # compulsory traffic per (observation, camera) at 16-bit: patches in + text in + out
         patches, text = a[0], a[1]
         units = patches.shape[0]
         p, d = (k.get("n_patches") or patches.shape[1]), patches.shape[2]
         kq = text.shape[1]
-        return units * (p * d * 2 + kq * d * 4 + kq * d * 4)
+        return units * (p * d * 2 + kq * d * 2 + kq * d * 2)
 
     ops.gemm = gemm_wrapper
     ops.text_aware_pool = timed("tave", real_tave, tave_bytes)
@@ -198,9 +275,10 @@ def pool_saturated(device, dtype, units: int = 2048, reps: int = 10):
     e1.record()
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / reps
-    nbytes = units * (p * d * 2 + kq * d * 4 + kq * d * 4)
-    gbs = nbytes / (us * 1e-6) / 1e9
-    return {"units": units, "avg_launch_us": us, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS}
+    gbs = units * POOL_UNIT_BYTES / (us * 1e-6) / 1e9               # the algorithmic 439,296 B per unit
+    moved = units * (p * d * 2 + kq * d * 4 + kq * d * 4) / (us * 1e-6) / 1e9   # what this kernel moves: text in / out are fp32
+    return {"units": units, "avg_launch_us": us, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "bytes_per_unit": POOL_UNIT_BYTES,
+            "moved_gbs": moved, "moved_frac": moved / PEAK_HBM_GBS, "moved_bytes_per_unit": p * d * 2 + kq * d * 8}
 
 
 def library_gemm_rate(device, dtype, m: int = 32768, reps: int = 10):
@@ -243,6 +321,11 @@ def cpu_baseline(work: Workload, budget_s: float = 15.0):
             break
     return dict(value=n / el, unit="obs/s", cores=cores, kind="port",
                 sample=f"{n} single-episode observations (2 cams 224^2, default config, fp32 torch-CPU oracle, {el:.1f} s)")
+
+
+def timed_composition(steps: int) -> str:
+    fill = sum(1 for t in range(steps) if t % EPISODE_LEN < 12)
+    return f"{fill} fill + {steps - fill} slide steps"
 
 
 def main():
@@ -293,9 +376,13 @@ def main():
             "metric": "observations/sec (obs->action chunk)", "value": obs / elapsed, "unit": "obs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.clip_dtype, "data": "synthetic",
-            "config": {"workload": "OTTER inference (16-bit MFMA towers, fp32 MFMA policy), batch 64 two-camera 224^2 observations per GPU, history 12 with "
-                                   "GPU-resident KV cache (12 cached + 12 sliding steps per episode), default ViT-L/14 config, "
-                                   "random-init weights", "per_gpu_batch": PER_GPU_EPISODES, "parallelism": f"dp{world} (episodes sharded, no collective)"},
+            "config": {"workload": f"OTTER inference, batch 64 two-camera 224^2 observations per GPU, history 12 with GPU-resident KV cache; episodes of "
+                                   f"{EPISODE_LEN} steps (12 filling the cache + 12 sliding), the {args.steps} timed steps start at an episode boundary = "
+                                   f"{timed_composition(args.steps)}; default ViT-L/14 config, random-init weights; towers on 16-bit MFMA with "
+                                   f"{'fp16' if args.clip_dtype == 'f16' else 'bf16'} operands"
+                                   + (" (fp16, not bf16: same width and MFMA rate; bf16 operands miss the 1e-3 action tolerance, measured 1.2e-3 to 4e-3)"
+                                      if args.clip_dtype == "f16" else " (misses the 1e-3 action tolerance: parity is quoted on fp16)")
+                                   + ", fp32 MFMA policy", "per_gpu_batch": PER_GPU_EPISODES, "parallelism": f"dp{world} (episodes sharded, no collective)"},
         }
         if args.workload == "train":
             result["config"] = {"workload": "OTTER training step (frozen 16-bit MFMA towers, fp32 hand-written backward of the 31M trainable parameters, "
@@ -307,15 +394,12 @@ def main():
             gm = k["gemm"]
             # dominant kernel: the bf16 MFMA GEMM (CLIP tower launches are >99.9% of its FLOPs)
             tf = gm["total_work"] / (gm["total_ms"] * 1e-3) / 1e12
-            traffic = mfma_busy = None          # from the PMC passes of this same command (profiles/): bytes per launch, MFMA-busy share
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as fh:
-                    pmc = json.load(fh)
-                traffic, mfma_busy = pmc["traffic_bytes_per_launch"], pmc.get("mfma_busy_fraction_of_simd_cycles")
-            except (OSError, KeyError, ValueError):
-                pass
+            # hardware counters cannot be read from inside an un-profiled run: quoted from the PMC passes of this same
+            # command, and only while the kernel sources are the ones those passes ran (else null)
+            traffic, mfma_busy, pmc_source = pmc_counters_of_this_kernel()
             result["roofline"] = {"bound": "mfma", "kernel": "gemm_256x256 (16-bit operands, CLIP towers; whole 256-row tiles)", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
                                   "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": traffic,
+                                  "traffic_source": pmc_source,
                                   "algorithmic_bytes_per_launch": gm["total_bytes"] / gm["launches"], "pmc_mfma_busy_frac": mfma_busy,
                                   "launches": gm["launches"], "avg_launch_us": 1e3 * gm["total_ms"] / gm["launches"],
                                   "gemm_ms_per_step": gm["total_ms"] / 2}
@@ -328,7 +412,7 @@ def main():
             result["roofline_pool"] = {"bound": "hbm", "kernel": "tave_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                        "frac": gbs / PEAK_HBM_GBS, "traffic": None, "launches": tv["launches"],
                                        "avg_launch_us": 1e3 * tv["total_ms"] / tv["launches"],
-                                       "units_per_launch": 2 * work.n}
+                                       "units_per_launch": 2 * work.n, "bytes_per_unit": POOL_UNIT_BYTES}
             st = k["stats"]
             if st["launches"]:
                 sg = st["total_work"] / max(st["total_ms"] * 1e-3, 1e-12) / 1e9
@@ -337,6 +421,11 @@ def main():
                                                 "launches": st["launches"], "avg_launch_us": 1e3 * st["total_ms"] / st["launches"]}
             if world == 1 and args.workload == "infer" and not args.no_reference_points:
                 result["roofline_pool"]["saturated"] = pool_saturated(device, clip_dtype)
+        if world == 1 and args.workload == "infer" and not args.no_reference_points:
+            el = measure_with_h2d(work, args.steps)
+            result["value_incl_h2d"] = {"value": work.n * args.steps / el, "unit": "obs/s", "ms_per_step": 1e3 * el / args.steps,
+                                        "note": "same steps with the uint8 frames (19.3 MB per step) and proprioception uploaded from pinned host "
+                                                "memory every step on a copy stream, one step ahead; never the headline value"}
         if world == 1 and not args.no_cpu_baseline and args.workload == "infer":
             result["cpu_baseline"] = cpu_baseline(work)
         print(json.dumps(result))

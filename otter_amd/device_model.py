@@ -19,6 +19,7 @@ supplies device memory and the stream.  The arithmetic follows the reference's m
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -111,6 +112,10 @@ class ClipDevice:
         self.ln_final = (_f32(sd[prefix + "ln_final.weight"], device), _f32(sd[prefix + "ln_final.bias"], device))
         self.w_tproj = ops.pack_weight(sd[prefix + "text_projection"].float().t().contiguous(), dtype, device)
         self._text_cache: Dict[bytes, Tensor] = {}
+        # debugging aid (OTTER_DEBUG_STREAM=1): largest |value| of the residual stream after every block, so that a model whose
+        # activations approach fp16's range (conversions saturate at +-65504 silently) can be spotted; costs a sync per block
+        self.debug_stream = os.environ.get("OTTER_DEBUG_STREAM", "0") == "1"
+        self.stream_absmax: List[float] = []
 
     # -- shared block body -------------------------------------------------------------------
     def _run_blocks(self, x: Tensor, blocks: List[_Block], n_seq: int, seq_len: int, heads: int, causal: bool,
@@ -133,6 +138,8 @@ class ClipDevice:
                 h = ops.layernorm(x, *b.ln2, out_dtype=self.dtype)
                 m = ops.gemm(h, b.w_fc, b.n_fc, b.b_fc, act=self.act)
             ops.gemm(m, b.w_proj, b.width, b.b_proj, residual=x, out=x)
+            if self.debug_stream:
+                self.stream_absmax.append(float(x.abs().max()))
         return last if stop_after_last_attention else x
 
     # -- vision ------------------------------------------------------------------------------

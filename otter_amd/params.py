@@ -261,7 +261,31 @@ def attach(root: nn.Module, spec: ParamSpec, gen: torch.Generator) -> None:
         node.register_parameter(parts[-1], nn.Parameter(value, requires_grad=(spec.kind == "param")))
 
 
-def random_state_dict(specs: List[ParamSpec], seed: int = 0) -> Dict[str, Tensor]:
-    """A random-init checkpoint with the reference's initial distributions (not its RNG stream)."""
+def random_state_dict(specs: List[ParamSpec], seed: int = 0, outlier_channels: int = 0, outlier_scale: float = 60.0) -> Dict[str, Tensor]:
+    """A random-init checkpoint with the reference's initial distributions (not its RNG stream).
+
+    ``outlier_channels`` > 0 mimics what trained CLIP towers look like and N(0, sigma) weights do not: that many channels
+    of each tower's residual stream carry values ``outlier_scale`` times larger than the rest (the rows of every
+    ``out_proj`` / ``c_proj`` that write them are scaled up, bias included) while the LayerNorm gains that read them are
+    scaled down by the same factor.  Exercises range and rounding of a 16-bit residual stream and of LayerNorm folded into
+    16-bit weights."""
     g = torch.Generator().manual_seed(seed)
-    return {s.key: s.init(tuple(s.shape), g).to(torch.float32) for s in specs}
+    sd = {s.key: s.init(tuple(s.shape), g).to(torch.float32) for s in specs}
+    if outlier_channels > 0:
+        for tower in ("clip_model.visual.transformer.", "clip_model.transformer."):
+            keys = [k for k in sd if k.startswith(tower)]
+            if not keys:
+                continue
+            width = sd[tower + "resblocks.0.ln_1.weight"].numel()
+            ch = torch.randperm(width, generator=g)[:outlier_channels]
+            for k in keys:
+                if k.endswith(("attn.out_proj.weight", "mlp.c_proj.weight", "attn.out_proj.bias", "mlp.c_proj.bias")):
+                    sd[k][ch] *= outlier_scale
+                    if k.endswith(".bias"):
+                        sd[k][ch] += 0.5 * outlier_scale * torch.sign(torch.randn(len(ch), generator=g))   # a steady drift, as in trained towers
+                elif k.endswith(("ln_1.weight", "ln_2.weight")):
+                    sd[k][ch] /= outlier_scale
+            for k in ("clip_model.visual.ln_post.weight", "clip_model.ln_final.weight"):
+                if k in sd and sd[k].numel() == width:
+                    sd[k][ch] /= outlier_scale
+    return sd

@@ -1,0 +1,16 @@
+"""The pooling kernel alone at a chip-filling size (2048 (observation, camera) units), the launch bench.py's
+roofline_pool.saturated times: run under `rocprofv3 --kernel-trace --stats` to get the kernel's own duration."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    for dtype in (torch.float16,):
+        print(json.dumps(bench.pool_saturated(dev, dtype, units=2048, reps=20)))

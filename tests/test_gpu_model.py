@@ -122,6 +122,45 @@ def test_default_config_vit_l14_matches_oracle(dev):
     assert worst <= 1e-3
 
 
+@pytest.mark.parametrize("dtype,bound", [(torch.float16, 1e-3), (torch.bfloat16, 2e-3)])
+def test_outlier_channel_weights_vit_l14(dev, dtype, bound):
+    """Trained CLIP towers carry a few residual-stream channels tens of times larger than the rest, read through small
+    LayerNorm gains; N(0, sigma) weights never produce that.  Default configuration with 6 such channels per tower (x60):
+    the 16-bit residual stream and the LayerNorm folded into 16-bit weights against the fp32 oracle on the same weights.
+    (Parity for the PUBLISHED weights themselves stays unpinned: they are not available offline.)"""
+    from otter_amd.config import ModelConfig, SharedConfig
+    from otter_amd.otter import OTTER
+    from otter_amd.params import otter_specs, random_state_dict
+    mc, sc = ModelConfig(), SharedConfig()
+    sd = random_state_dict(otter_specs(mc, sc), seed=0, outlier_channels=6, outlier_scale=60.0)
+    model = OTTER(mc, sc)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    model.clip_compute_dtype = dtype
+    rng = np.random.default_rng(6)
+    images = torch.from_numpy(rng.integers(0, 256, (2, 3, 224, 224), dtype=np.uint8))
+    text = torch.zeros(77, dtype=torch.int32)
+    text[0], text[1:7], text[7] = 49406, torch.from_numpy(rng.integers(1, 49406, 6).astype(np.int32)), 49407
+    proprio = torch.from_numpy(rng.standard_normal(10).astype(np.float32))
+    clip = model.clip_device()
+    clip.debug_stream = True
+    pf, tf = model.extract_clip_features(images[None, None].to(dev), text[None])
+    clip.debug_stream = False
+    with torch.no_grad():
+        ref_pf = clip_ref.patch_features(R.clip_transform(images), sd)
+        ref_tf = clip_ref.text_features(text[None], 15, sd)
+    cos_patch = min(_cos(pf[c][0].cpu(), ref_pf[c]) for c in range(2))
+    cos_text = _cos(tf[0].cpu(), ref_tf[0])
+    ref = R.Rollout(sd, R.Dims()).step(R.clip_transform(images), text, proprio).numpy()
+    got = model.forward_inference(images.to(dev), text, proprio.to(dev)).cpu().numpy()
+    err = float(np.abs(got - ref).max())
+    peak = max(clip.stream_absmax)
+    print(f"outlier weights, {dtype}: residual stream peaks at {peak:.0f} (typical element ~1), patch cosine {cos_patch:.6f}, "
+          f"text cosine {cos_text:.6f}, max |action - oracle| = {err:.2e}")
+    assert peak > 100 and peak < 65504                 # the stream really carries outliers, and stays inside fp16's range
+    assert cos_patch >= 0.9999 and cos_text >= 0.9999 and err <= bound
+
+
 @pytest.mark.parametrize("clip_model,res", [("ViT-B/16", 224), ("ViT-B/32", 224), ("ViT-L/14@336px", 336)])
 def test_other_clip_backbones_match_oracle(dev, clip_model, res):
     """The other CLIP ViTs the reference's config accepts: 196 / 49 / 576 patches (the first two are not whole 16-patch
@@ -397,7 +436,7 @@ def test_small_batch_encoder_graph_matches_eager(dev, monkeypatch):
 
 def test_bf16_towers_and_batch_independence(dev):
     """bfloat16 operands for the towers (the alternative to the fp16 default): visual tokens still reach cosine 0.9999
-    against the fp32 oracle; actions carry bf16's 8x larger rounding (documented bound 4e-3, the fp16 default is held
+    against the fp32 oracle; actions carry bf16's 8x larger rounding (measured 1.4e-3, bound 2e-3: bf16 operands MISS the path's 1e-3 tolerance, which is why fp16 is the default and the configuration every number is quoted on; the fp16 default is held
     to 1e-3 above).  Also: an observation's result does not depend on the batch it is computed in (bit for bit)."""
     from otter_amd.config import ModelConfig, SharedConfig
     mc, sc = ModelConfig(), SharedConfig()
@@ -416,6 +455,6 @@ def test_bf16_towers_and_batch_independence(dev):
         ref = R.forward(images[:1], text[:1], proprio[:1], sd, R.Dims())
     err = (acts[:1] - ref).abs().max().item()
     print(f"bf16 towers: max |action - oracle| = {err:.2e}")
-    assert err <= 4e-3
+    assert err <= 2e-3            # measured 1.4e-3; the fp16 default is held to 1e-3 (the path's tolerance) above
     alone = model(images[2:3].to(dev), text[2:3], proprio[2:3].to(dev)).cpu()
     torch.testing.assert_close(alone[0], acts[2], rtol=0, atol=5e-4)       # batch independent up to the split-K summation order

@@ -43,26 +43,37 @@ def _hf_to_openai(hf_sd, n_vis, n_txt):
     return sd
 
 
+# toy width, and the real ViT-L/14 geometry (width 1024 / 16 heads / 257 tokens; text width 768 / 12 heads) at 2 layers
+GEOMETRIES = {
+    "toy": dict(tw=128, ti=512, tl=2, th=2, vw=128, vi=512, vl=3, vh=2, res=56, proj=64, n_img=3),
+    "vit_l14_geometry": dict(tw=768, ti=3072, tl=2, th=12, vw=1024, vi=4096, vl=2, vh=16, res=224, proj=768, n_img=2),
+}
+
+
+@pytest.mark.parametrize("geometry", list(GEOMETRIES))
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
-def test_clip_towers_match_transformers(act):
+def test_clip_towers_match_transformers(act, geometry):
     from transformers import CLIPConfig, CLIPModel
+    g = GEOMETRIES[geometry]
+    if geometry != "toy" and act == "gelu":
+        pytest.skip("the activation is covered at the toy width")
     torch.manual_seed(0)
     cfg = CLIPConfig(
-        text_config=dict(hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+        text_config=dict(hidden_size=g["tw"], intermediate_size=g["ti"], num_hidden_layers=g["tl"], num_attention_heads=g["th"],
                          vocab_size=49408, max_position_embeddings=77, hidden_act=act, eos_token_id=49407,
                          bos_token_id=49406, pad_token_id=0),
-        vision_config=dict(hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
-                           image_size=56, patch_size=14, hidden_act=act),
-        projection_dim=64)
+        vision_config=dict(hidden_size=g["vw"], intermediate_size=g["vi"], num_hidden_layers=g["vl"], num_attention_heads=g["vh"],
+                           image_size=g["res"], patch_size=14, hidden_act=act),
+        projection_dim=g["proj"])
     hf = CLIPModel(cfg).eval()
     # give biases / LN parameters non-trivial values
     with torch.no_grad():
         for p_ in hf.parameters():
             if p_.dim() == 1:
                 p_.add_(torch.randn_like(p_) * 0.1)
-    sd = _hf_to_openai(hf.state_dict(), 3, 2)
+    sd = _hf_to_openai(hf.state_dict(), g["vl"], g["tl"])
     f = clip_ref.quick_gelu if act == "quick_gelu" else clip_ref.gelu_erf
-    images = torch.randn(3, 3, 56, 56)
+    images = torch.randn(g["n_img"], 3, g["res"], g["res"])
     tokens = torch.zeros(2, 77, dtype=torch.long)
     tokens[0, :5] = torch.tensor([49406, 5, 77, 901, 49407])
     tokens[1, :9] = torch.tensor([49406, 15, 7, 91, 3, 1000, 40000, 2, 49407])
@@ -81,6 +92,7 @@ def test_clip_towers_match_transformers(act):
         txt = clip_ref.encode_text(tokens, sd, act=f)
         last = clip_ref.vision_last_attn(images, sd, act=f)
     hook.remove()
+    assert last.shape == (g["n_img"], (g["res"] // 14) ** 2 + 1, g["vw"])
     np.testing.assert_allclose(img.numpy(), img_hf.numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(txt.numpy(), txt_hf.numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(last.numpy(), captured["attn"].numpy(), rtol=1e-4, atol=1e-5)

@@ -159,6 +159,18 @@ def measure_with_h2d(work: "Workload", steps: int) -> float:
     return time.perf_counter() - t0
 
 
+class StubWorkload:
+    """OTTER_BENCH_STUB=1: the launch wiring of this file (rank / world parsing, process group, fenced timing, rank-0 JSON
+    line, tear-down) rehearsed on a machine without GPUs -- a step sleeps instead of computing.  Never a measurement."""
+
+    def __init__(self, rank: int):
+        self.n, self.rank, self.t = PER_GPU_EPISODES, rank, 0
+
+    def step(self):
+        time.sleep(0.002 * (1 + self.rank))
+        self.t += 1
+
+
 class TrainWorkload:
     """Training step of the reference's data-parallel configuration: global batch 128 windows over 8 GPUs = 16 windows of
     12 observations per GPU and step (384 camera images), frozen towers + hand-written backward of the 31 M trainable
@@ -351,23 +363,31 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     # One process per GPU.  OTTER_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks
     # share the visible devices and synchronise through the host (RCCL refuses two ranks on one device).
-    backend = os.environ.get("OTTER_BENCH_BACKEND", "nccl")
-    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    stub = os.environ.get("OTTER_BENCH_STUB", "0") == "1"
+    backend = "gloo" if stub else os.environ.get("OTTER_BENCH_BACKEND", "nccl")
     import torch.distributed as dist
+    if stub:
+        device = torch.device("cpu")
+    else:
+        local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
     sync_device = device if backend == "nccl" else torch.device("cpu")
 
     clip_dtype = torch.float16 if args.clip_dtype == "f16" else torch.bfloat16
-    work = Workload(device, seed=rank, clip_dtype=clip_dtype) if args.workload == "infer" else TrainWorkload(device, seed=rank, clip_dtype=clip_dtype)
+    if stub:
+        work = StubWorkload(rank)
+        args.no_kernel_timing = args.no_cpu_baseline = args.no_reference_points = True
+    else:
+        work = Workload(device, seed=rank, clip_dtype=clip_dtype) if args.workload == "infer" else TrainWorkload(device, seed=rank, clip_dtype=clip_dtype)
     from otter_amd.sharding import timed_region
     for _ in range(args.warmup):
         work.step()
     work.t = 0                                           # timed region starts at an episode boundary
     # barrier + device sync on both sides of exactly `steps` steps; MAX over ranks
-    elapsed = timed_region(work.step, args.steps, world=world, sync=torch.cuda.synchronize, device=sync_device)
+    elapsed = timed_region(work.step, args.steps, world=world, sync=(lambda: None) if stub else torch.cuda.synchronize, device=sync_device)
 
     result = None
     if rank == 0:
@@ -375,7 +395,7 @@ def main():
         result = {
             "metric": "observations/sec (obs->action chunk)", "value": obs / elapsed, "unit": "obs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.clip_dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.clip_dtype, "data": "synthetic" if not stub else "none (OTTER_BENCH_STUB rehearsal: no compute)",
             "config": {"workload": f"OTTER inference, batch 64 two-camera 224^2 observations per GPU, history 12 with GPU-resident KV cache; episodes of "
                                    f"{EPISODE_LEN} steps (12 filling the cache + 12 sliding), the {args.steps} timed steps start at an episode boundary = "
                                    f"{timed_composition(args.steps)}; default ViT-L/14 config, random-init weights; towers on 16-bit MFMA with "
@@ -384,7 +404,7 @@ def main():
                                       if args.clip_dtype == "f16" else " (misses the 1e-3 action tolerance: parity is quoted on fp16)")
                                    + ", fp32 MFMA policy", "per_gpu_batch": PER_GPU_EPISODES, "parallelism": f"dp{world} (episodes sharded, no collective)"},
         }
-        if args.workload == "train":
+        if args.workload == "train" and not stub:
             result["config"] = {"workload": "OTTER training step (frozen 16-bit MFMA towers, fp32 hand-written backward of the 31M trainable parameters, "
                                             "flat-buffer gradient all-reduce, AdamW), 16 windows x 12 two-camera 224^2 observations per GPU, "
                                             "default ViT-L/14 config, random-init weights", "per_gpu_batch": work.n,

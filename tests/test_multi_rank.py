@@ -93,3 +93,141 @@ def test_gradient_exchange_two_ranks_gloo(tmp_path):
     want = torch.arange(1000, dtype=torch.float32) * 3
     for r in range(2):
         assert torch.equal(torch.load(tmp_path / f"g{r}.pt"), want)
+
+
+def test_bench_launch_wiring_two_ranks(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), with the device step
+    stubbed (OTTER_BENCH_STUB=1: gloo, a step sleeps): rank / world parsing, process group, fenced max-over-ranks timing,
+    exactly one JSON line from rank 0, clean tear-down."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OTTER_BENCH_STUB="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak" and out["higher_is_better"]
+    assert out["unit"] == "obs/s" and out["vs_baseline"] is None and "dp2" in out["config"]["parallelism"]
+    # whole-job rate: both ranks' observations over the SLOWEST rank's time (rank 1 sleeps 4 ms per step, rank 0 2 ms)
+    assert out["ms_per_step"] >= 4.0
+    assert out["value"] == pytest.approx(2 * 64 * 6 / (out["ms_per_step"] * 6 / 1e3), rel=1e-6)
+    # a world-size mismatch is refused before anything is initialised
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "needs torchrun" in (bad.stderr + bad.stdout)
+
+
+# ---------------------------------------------------------------------------------- data-parallel Trainer on two ranks
+class _HostKernels:
+    """The three device kernels Trainer.step launches, in torch on the host, so that the step's own logic (flat buffers,
+    bucketed exchange, 1 / (scale * world) fold, skip-on-overflow, schedule) runs unchanged on CPU ranks."""
+
+    def __init__(self, real):
+        self._lib = real._lib
+
+    @staticmethod
+    def grad_stats(x, workspace=None):
+        finite = torch.isfinite(x)
+        return torch.stack([(x[finite].double() ** 2).sum().float(), (~finite).sum().float()])
+
+    @staticmethod
+    def adamw_step(p, g, m, v, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay, step, inv_scale=1.0, skip_flag=None):
+        if skip_flag is not None and float(skip_flag) != 0:
+            return
+        g = g * inv_scale
+        p.mul_(1 - lr * weight_decay)
+        m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+        v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+        denom = (v.sqrt() / (1 - betas[1] ** step) ** 0.5).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / (1 - betas[0] ** step))
+
+
+def _dp_case():
+    import golden_inputs as GI
+    from oracle import otter_ref as R
+    case = dict(GI.E2E_CASES[0], B=4)                      # 4 windows: 2 per rank
+    mc, sc = GI.e2e_configs(case)
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length, num_cameras=len(sc.camera_keys),
+                  pool_true_text=mc.pool_true_text, use_mse=sc.mse_loss)
+    return case, mc, sc, dims, GI.e2e_inputs(case)
+
+
+def _oracle_forward_backward(model, dims):
+    """Stand-in for TrainableTail.forward_backward: the fp32 CPU oracle differentiated by torch autograd."""
+    from oracle import otter_ref as R
+
+    def fb(images, ids, proprio, gt, mask, grads, grad_scale=1.0):
+        sd = dict(model.state_dict(keep_vars=True))
+        loss = R.forward(images, ids, proprio, sd, dims, gt)
+        names = list(grads)
+        for n, g in zip(names, torch.autograd.grad(loss * grad_scale, [sd[n] for n in names])):
+            grads[n].add_(g)
+        return loss.detach().view(1)
+    return fb
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from otter_amd import ops
+        from otter_amd.otter import OTTER
+        from otter_amd.params import otter_specs, random_state_dict
+        from otter_amd.trainer import Trainer
+        case, mc, sc, dims, (images, text, proprio, gt) = _dp_case()
+        model = OTTER(mc, sc)
+        model.load_state_dict(random_state_dict(otter_specs(mc, sc), seed=case["seed"]), strict=True)
+        tr = Trainer(model, lr=3e-4, weight_decay=0.01, warmup_steps=1, num_steps=20, bucket_elems=100_000)
+        assert tr.world == world
+        tr.ops = _HostKernels(ops)
+        tr.tail.forward_backward = _oracle_forward_backward(model, dims)
+        lo, hi = episode_shard(images.shape[0], rank, world)          # per-rank batch = global / world (script/train.py:152)
+        log = [tr.step(images[lo:hi], text[lo:hi], proprio[lo:hi], gt[lo:hi]) for _ in range(3)]
+        torch.save({"flat": tr.flat_p.clone(), "log": log, "names": {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}},
+                   os.path.join(out_dir, f"t{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_match_single_process_training(tmp_path):
+    """Two data-parallel ranks (gloo), each with half of the windows, through Trainer.step's real exchange (bucketed SUM
+    all-reduce, mean folded into the unscale factor, loss scaling, schedule) end up with the parameters that ONE process
+    reaches with torch.optim.AdamW on the whole batch -- DistributedDataParallel's contract (script/train.py:116-119,
+    otter/util/misc.py:334-345)."""
+    from oracle import otter_ref as R
+    from otter_amd.params import otter_specs, random_state_dict
+    from otter_amd.trainer import cosine_with_warmup
+    mp.spawn(_trainer_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(tmp_path / f"t{r}.pt", weights_only=False) for r in range(2)]
+    assert torch.equal(res[0]["flat"], res[1]["flat"])                 # replicas stay bit-identical
+    case, mc, sc, dims, (images, text, proprio, gt) = _dp_case()
+    sd = random_state_dict(otter_specs(mc, sc), seed=case["seed"])
+    names = list(res[0]["names"])
+    sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    decay = [sdg[n] for n in names if not (sdg[n].dim() == 1 or n.endswith(".bias"))]
+    no_decay = [sdg[n] for n in names if (sdg[n].dim() == 1 or n.endswith(".bias"))]
+    opt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.01}], lr=3e-4)
+    for it in range(3):
+        for grp in opt.param_groups:
+            grp["lr"] = 3e-4 * cosine_with_warmup(it, 1, 20)
+        opt.zero_grad()
+        loss = R.forward(images, text, proprio, sdg, dims, gt)
+        loss.backward()
+        norm = sum(float((p.grad.double() ** 2).sum()) for p in decay + no_decay) ** 0.5
+        opt.step()
+        # each rank logs its own shard's loss; the mean over ranks is the global loss; the norm is that of the MEAN gradient
+        shard_mean = 0.5 * (res[0]["log"][it]["loss"] + res[1]["log"][it]["loss"])
+        assert abs(shard_mean - loss.item()) <= 1e-5
+        assert res[0]["log"][it]["grad_norm"] == pytest.approx(norm, rel=1e-4)
+        assert not res[0]["log"][it]["skipped"] and res[0]["log"][it]["lr"] == pytest.approx(3e-4 * cosine_with_warmup(it, 1, 20))
+    # Adam normalises every element's step to ~lr (two steps of 3e-4 here), so fp32 summation-order noise in a tiny gradient
+    # shows up magnified.  (A wrong mean would hide here -- Adam is invariant to the gradient's scale -- and is caught by
+    # the gradient-norm comparison above; a missing exchange by the replicas' bit-equality.)
+    worst = max((res[0]["names"][n] - sdg[n].detach()).abs().max().item() for n in names)
+    assert worst <= 3e-5, worst

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 9
+#define OTTER_HIP_ABI_VERSION 10
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -258,6 +258,24 @@ int otter_text_aware_pool_temperature_grad(int dtype, const void* patches, long 
 int otter_resize_bicubic_u8(const unsigned char* src, int n, int src_h, int src_w, int y0, int x0, int crop_h, int crop_w,
                             const int* h_bounds, const int* h_coef, int h_ksize, const int* v_bounds, const int* v_coef,
                             int v_ksize, unsigned char* tmp, unsigned char* out, int out_size, void* stream);
+
+/* Action post-processing of one control step for n_episodes concurrent episodes, fp64 like the reference's host numpy:
+ *   (1) delta chunk -> absolute chunk relative to the current pose: OtterInference._decode_actions
+ *       (otter/policy/otter_interface.py:113-133) = convert_abs_action (otter/dataset/utils.py:236-264, with
+ *       rot_6d_to_rot_mat / gram_schmidt :19-34,100-119): t = R_cur . dt + t_cur, R = R_cur . R_delta;
+ *   (2) which action to execute now: OTTERRolloutPolicy.__call__ (script/droid_inference.py:174-196) -- temporal
+ *       ensemble over the last exec_horizon chunks with weights exp(k * i), i = 0 for the oldest (k = 0.05 upstream), or,
+ *       receding != 0, the next element of a chunk that is replaced every exec_horizon steps;
+ *   (3) action_10d_to_7d (dataset/utils.py:145-151) + `gripper > 0.5` (droid_inference.py:198-199).
+ * delta_chunks: fp32 [E][horizon][10] (the policy's output); cur_pose: fp64 [E][10] = xyz, first two rows of the current
+ * rotation matrix, gripper (what _proprocess_proprio stores, otter_interface.py:60-84).
+ * State, owned by the caller: ring fp64 [E][exec_horizon][exec_horizon][10] and counts int32 [E] (chunks pushed since the
+ * episode began: zero an episode's count to restart it; the kernel increments it).
+ * Outputs: abs_chunks fp64 [E][horizon][10] (may be NULL), action10 fp64 [E][10] (may be NULL), robot7 fp64 [E][7] =
+ * xyz, Euler XYZ, gripper as 0/1. */
+int otter_action_step(const float* delta_chunks, const double* cur_pose, double* abs_chunks, double* ring, int* counts,
+                      double* action10, double* robot7, int n_episodes, int horizon, int action_dim, int exec_horizon,
+                      int receding, double k, void* stream);
 
 #ifdef __cplusplus
 }

@@ -475,6 +475,31 @@ def window_append(src: Tensor, fresh: Tensor, dst: Tensor, lens_in: Tensor, lens
     _lib.call("otter_window_append", _ptr(src), _ptr(fresh), _ptr(dst), _ptr(lens_in), _ptr(lens_out), b, s, dim, _stream())
 
 
+def action_step(delta_chunks: Tensor, cur_pose: Tensor, ring: Tensor, counts: Tensor, exec_horizon: int, receding: bool,
+                k: float = 0.05, want_abs: bool = False):
+    """One control step of many episodes: delta chunks fp32 (E, H, 10) + current poses fp64 (E, 10) ->
+    (robot actions fp64 (E, 7), executed 10-d actions fp64 (E, 10), absolute chunks fp64 (E, H, 10) or None).
+    ``ring`` fp64 (E, X, X, 10) and ``counts`` int32 (E,) are the queue state (see ``otter_action_step``)."""
+    _chk(delta_chunks, torch.float32, "action_step.delta", 3)
+    _chk(cur_pose, torch.float64, "action_step.pose", 2)
+    _chk(ring, torch.float64, "action_step.ring", 4)
+    _chk(counts, torch.int32, "action_step.counts", 1)
+    e, h, a = delta_chunks.shape
+    x = int(exec_horizon)
+    if tuple(cur_pose.shape) != (e, a) or tuple(ring.shape) != (e, x, x, a) or counts.numel() != e:
+        raise ValueError(f"action_step: delta {tuple(delta_chunks.shape)}, pose {tuple(cur_pose.shape)}, ring {tuple(ring.shape)}, counts {tuple(counts.shape)}")
+    for t in (delta_chunks, cur_pose, ring, counts):
+        if not t.is_contiguous():
+            raise ValueError("action_step: operands must be contiguous")
+    dev = delta_chunks.device
+    robot = torch.empty(e, 7, dtype=torch.float64, device=dev)
+    act10 = torch.empty(e, a, dtype=torch.float64, device=dev)
+    abs_chunks = torch.empty(e, h, a, dtype=torch.float64, device=dev) if want_abs else None
+    _lib.call("otter_action_step", _ptr(delta_chunks), _ptr(cur_pose), _ptr(abs_chunks), _ptr(ring), _ptr(counts), _ptr(act10), _ptr(robot),
+              e, h, a, x, int(bool(receding)), float(k), _stream())
+    return robot, act10, abs_chunks
+
+
 # ------------------------------------------------------------------------------------------------------ training step
 def _f32_2d(t: Tensor, name: str):
     _chk(t, torch.float32, name, 2)

@@ -4,7 +4,9 @@ predicted chunks is executed at each control step.
 Two modes, as upstream: receding-horizon control (execute the first ``action_exec_horizon`` actions of a chunk, then
 predict again) and temporal ensembling (every step predicts a chunk; the action executed now is the
 exponentially weighted mean of what the last ``action_exec_horizon`` chunks predicted for this step, weights
-``exp(k * i)`` with i = 0 for the oldest chunk, k = 0.05).  Host-side numpy: a few hundred bytes per step.
+``exp(k * i)`` with i = 0 for the oldest chunk, k = 0.05).  :class:`ActionQueue` / :class:`RolloutPolicy` are the
+single-episode host form (numpy, as upstream); :class:`DeviceActionQueue` / :class:`BatchedRolloutPolicy` do the same for
+many concurrent episodes in one kernel launch per control step, chunks and queue state never leaving the GPU.
 """
 from __future__ import annotations
 
@@ -46,6 +48,73 @@ class ActionQueue:
         now = np.stack([q.popleft() for q in self._queue])          # what every live chunk predicted for this step
         w = np.exp(self.k * np.arange(now.shape[0]))
         return (now * (w / w.sum())[:, None]).sum(axis=0)
+
+
+class DeviceActionQueue:
+    """:class:`ActionQueue` + ``convert_abs_action`` + :func:`to_robot_action` for ``n_episodes`` episodes on the GPU
+    (``otter_action_step``): the predicted delta chunks go in as they come out of the policy, 7-d robot actions come out."""
+
+    def __init__(self, n_episodes: int, action_exec_horizon: int, device, receding_horizon_control: bool = False, k: float = 0.05,
+                 action_dim: int = 10):
+        import torch
+        if action_exec_horizon < 1:
+            raise ValueError("action_exec_horizon must be at least 1")
+        self.n, self.horizon, self.receding, self.k = int(n_episodes), int(action_exec_horizon), bool(receding_horizon_control), float(k)
+        self.ring = torch.zeros(self.n, self.horizon, self.horizon, action_dim, dtype=torch.float64, device=device)
+        self.counts = torch.zeros(self.n, dtype=torch.int32, device=device)
+
+    def clear(self, episode_ids=None) -> None:
+        if episode_ids is None:
+            self.counts.zero_()
+        else:
+            import torch
+            self.counts.index_fill_(0, torch.as_tensor(list(episode_ids), dtype=torch.long, device=self.counts.device), 0)
+
+    def step(self, delta_chunks, cur_pose, want_abs: bool = False):
+        """delta_chunks fp32 (n, H, 10) on the device, cur_pose fp64 (n, 10) -> (robot (n, 7), executed (n, 10), abs chunks or None)."""
+        from . import ops
+        return ops.action_step(delta_chunks.contiguous(), cur_pose, self.ring, self.counts, self.horizon, self.receding, self.k, want_abs)
+
+
+def poses_to_proprio(cartesian: np.ndarray, gripper: np.ndarray) -> np.ndarray:
+    """``OtterInference._proprocess_proprio`` (``otter_interface.py:60-84``) for a batch: (n, 6) xyz + Euler XYZ and (n,) or
+    (n, 1) gripper -> (n, 10) float64 = xyz, first two rows of the rotation matrix, gripper clipped to [0, 1]."""
+    from scipy.spatial.transform import Rotation
+    cartesian = np.asarray(cartesian, dtype=np.float64).reshape(-1, 6)
+    rot = Rotation.from_euler("XYZ", cartesian[:, 3:]).as_matrix()[:, :2, :].reshape(-1, 6)
+    grip = np.clip(np.asarray(gripper, dtype=np.float64).reshape(-1, 1), 0, 1)
+    return np.concatenate([cartesian[:, :3], rot, grip], axis=-1)
+
+
+class BatchedRolloutPolicy:
+    """Many robots / simulated episodes behind one model: frames, poses and grippers of ``n`` episodes in, ``n`` 7-d robot
+    actions out per control step.  The encoder, the policy with its GPU-resident history, the absolute-action decode, the
+    action queue and the 10-d -> 7-d conversion all run on the device; per step the host uploads frames + poses and reads
+    back (n, 7) doubles."""
+
+    def __init__(self, model, n_episodes: int, action_exec_horizon: int, receding_horizon_control: bool = False):
+        from .engine import BatchedRollout
+        if action_exec_horizon > model.action_horizon:
+            raise ValueError(f"action_exec_horizon must be at most the predicted horizon ({model.action_horizon})")
+        self.model = model
+        self.dev = model.device_model()
+        self.rollout = BatchedRollout(self.dev, n_episodes)
+        self.queue = DeviceActionQueue(n_episodes, action_exec_horizon, self.dev.device, receding_horizon_control, action_dim=model.action_dim)
+        self.n = int(n_episodes)
+
+    def start_episodes(self, episode_ids=None) -> None:
+        self.rollout.reset(episode_ids)
+        self.queue.clear(episode_ids)
+
+    def __call__(self, frames, token_ids, cartesian: np.ndarray, gripper: np.ndarray):
+        """frames uint8 (n*cams, 3, R, R) on the device (camera order = sorted camera keys; :func:`vision_tf.crop_resize_device`
+        makes them from raw camera frames), token_ids int32 (n, 77) on the host, cartesian (n, 6), gripper (n,) ->
+        robot actions fp64 (n, 7) on the device."""
+        import torch
+        pose = torch.from_numpy(poses_to_proprio(cartesian, gripper)).to(self.dev.device)
+        text = self.dev.clip.text_tokens_cached(token_ids)
+        chunks = self.rollout.step(frames, text, pose.float())
+        return self.queue.step(chunks, pose)[0]
 
 
 def to_robot_action(action_10d: np.ndarray) -> np.ndarray:

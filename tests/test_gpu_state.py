@@ -170,3 +170,66 @@ def test_two_encoder_graphs_replayed_on_two_streams(dev):
     for e in range(2):
         for t in range(steps):
             assert torch.equal(outs[e][t], serial[e][t]), (e, t)
+
+
+@pytest.mark.parametrize("receding", [False, True])
+def test_device_action_queue_matches_the_host_queue(dev, receding):
+    """convert_abs_action + temporal ensemble / receding horizon + 10-d -> 7-d for 9 episodes in one launch per control
+    step, against the single-episode host code (numpy float64, itself held to the reference's outputs) run per episode;
+    a subset of the episodes restarts in the middle."""
+    from otter_amd.action_utils import convert_abs_action
+    from otter_amd.rollout_server import ActionQueue, DeviceActionQueue, poses_to_proprio, to_robot_action
+    n, H, X, steps = 9, 12, 5, 17
+    rng = np.random.default_rng(4)
+    dq = DeviceActionQueue(n, X, dev, receding_horizon_control=receding)
+    hq = [ActionQueue(X, receding) for _ in range(n)]
+    worst7 = worst10 = worst_abs = 0.0
+    for s in range(steps):
+        if s == 8:
+            dq.clear([2, 5])
+            hq[2].clear(); hq[5].clear()
+        delta = rng.standard_normal((n, H, 10)).astype(np.float32) * 0.3
+        delta[..., 3:9] += np.array([1, 0, 0, 0, 1, 0], dtype=np.float32)          # rotations near the identity, not orthonormal
+        delta[..., 9] = rng.uniform(0, 1, (n, H))
+        pose = poses_to_proprio(rng.standard_normal((n, 6)) * 0.5, rng.uniform(-0.2, 1.2, n))
+        robot, act10, abs_chunks = dq.step(torch.from_numpy(delta).to(dev), torch.from_numpy(pose).to(dev), want_abs=True)
+        robot, act10, abs_chunks = robot.cpu().numpy(), act10.cpu().numpy(), abs_chunks.cpu().numpy()
+        for e in range(n):
+            # (float64 in: on float32 chunks the host orthonormalises the delta rotation in float32, 2e-7 away from this)
+            ref_abs = convert_abs_action(delta[e][None].astype(np.float64), pose[e][None, None])[0]      # what OtterInference returns
+            worst_abs = max(worst_abs, float(np.abs(abs_chunks[e] - ref_abs).max()))
+            queue = hq[e]
+            ref10 = queue.next_action(ref_abs) if (not receding or queue.needs_prediction()) else queue.next_action(None)
+            worst10 = max(worst10, float(np.abs(act10[e] - ref10).max()))
+            ref7 = to_robot_action(ref10)                      # (orthonormalises the rotation rows of its argument in place, as upstream)
+            worst7 = max(worst7, float(np.abs(robot[e] - ref7).max()))
+            assert robot[e, 6] == ref7[6] and robot[e, 6] in (0.0, 1.0)
+    print(f"device action queue (receding={receding}): abs chunks {worst_abs:.1e}, executed 10-d {worst10:.1e}, robot 7-d {worst7:.1e}")
+    assert worst_abs <= 1e-12 and worst10 <= 1e-12 and worst7 <= 1e-9
+    assert dq.counts.cpu().tolist() == [steps if e not in (2, 5) else steps - 8 for e in range(n)]
+
+
+def test_batched_rollout_policy_end_to_end(dev):
+    """Frames + poses of 3 concurrent episodes -> 7-d robot actions, everything between on the device; episode 1 against
+    the single-episode chain OtterInference-style decode + host ActionQueue fed from the same model."""
+    from otter_amd.action_utils import convert_abs_action
+    from otter_amd.rollout_server import ActionQueue, BatchedRolloutPolicy, poses_to_proprio, to_robot_action
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    n, X = 3, 3
+    pol = BatchedRolloutPolicy(model, n, X)
+    rng = np.random.default_rng(12)
+    text = GI._tokens(rng, n, (4, 6, 9))
+    queue = ActionQueue(X)
+    model.reset_cache()
+    for s in range(sc.seq_length + 2):
+        frames = torch.from_numpy(rng.integers(0, 256, (n * 2, 3, sc.image_size, sc.image_size), dtype=np.uint8)).to(dev)
+        cart, grip = rng.standard_normal((n, 6)) * 0.4, rng.uniform(0, 1, n)
+        got = pol(frames, text, cart, grip).cpu().numpy()
+        pose = poses_to_proprio(cart, grip)
+        chunk = model.forward_inference(frames[2:4], text[1], torch.from_numpy(pose[1]).float().to(dev)).cpu().numpy()
+        ref = to_robot_action(queue.next_action(convert_abs_action(chunk[None].astype(np.float64), pose[1][None, None])[0]))
+        assert got.shape == (n, 7) and np.abs(got[1] - ref).max() <= 1e-4
+    pol.start_episodes([1])
+    assert pol.queue.counts.cpu().tolist() == [sc.seq_length + 2, 0, sc.seq_length + 2] and pol.rollout.lens_host[1] == 0

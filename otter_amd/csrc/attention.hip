@@ -29,15 +29,143 @@ __device__ __forceinline__ int v_swz(int row, int chunk) { return chunk ^ (((row
 // NT = number of 16-key tiles computed (also the number of 16-query tiles); LS = the sequence length when it is
 // known at compile time (0: taken from the arguments).  With LS the validity of every key is a compile-time fact
 // except in the last, partial tile, so the softmax carries no masking work for the full tiles.
+//
+// The three phases of one 16-query tile, shared by the two kernels below.  Lane (g, li) owns query column li.
+
+// S^T = K . Q^T for all NT key tiles.  A wave issues in order and has at most one partner wave on its SIMD, so LDS
+// latency is hidden by hand: the K fragments of the next batch of key tiles are requested before the MFMAs of the
+// current batch are issued.  Every key tile is computed, also rows past L: a wave-uniform skip would put a branch
+// between an MFMA and the first read of its accumulator.
+template <typename T, int NT>
+__device__ __forceinline__ void tile_scores(const char* sK, int k_row, int k_sw, int g, const typename Half16<T>::v8 (&qf)[2], f32x4 (&s)[NT]) {
+    typedef typename Half16<T>::v8 v8;
+    constexpr int KB = 4, NB = (NT + KB - 1) / KB;
+    v8 kf[2][KB][2];
+    auto read_k = [&](int b, v8 (&dst)[KB][2]) {
+#pragma unroll
+        for (int i = 0; i < KB; ++i)
+            if (b * KB + i < NT) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    dst[i][ks] = *(const v8*)(sK + (b * KB + i) * 2048 + k_row + (((ks * 4 + g) ^ k_sw) << 4));
+            }
+    };
+    read_k(0, kf[0]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) read_k(b + 1, kf[(b + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < KB; ++i)
+            if (b * KB + i < NT) {
+                const int kt = b * KB + i;
+                s[kt] = Half16<T>::mfma32(kf[b & 1][i][0], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f});
+            }
+#pragma unroll
+        for (int i = 0; i < KB; ++i)
+            if (b * KB + i < NT) {
+                const int kt = b * KB + i;
+                s[kt] = Half16<T>::mfma32(kf[b & 1][i][1], qf[1], s[kt]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// mask + exponentials over keys (per lane: one query); key kt*16 + 4g + r is valid iff kt*16 + r < lim.  The row sums come
+// from the matrix pipe in tile_pv (an all-ones A operand against the same P fragments that multiply V: nine MFMAs instead
+// of 68 VALU additions, in a loop whose pace the vector issue port sets), so the normaliser is the sum of exactly the
+// rounded probabilities that are multiplied into V.
+template <int NT, int LS>
+__device__ __forceinline__ void tile_softmax(f32x4 (&s)[NT], int lim, float c2) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool known_valid = LS && (kt * 16 + 15 < LS);      // every lane's key of this tile is < L
+            if (!known_valid) s[kt][r] = (kt * 16 + r < lim) ? s[kt][r] : -INFINITY;
+            mx = fmaxf(mx, s[kt][r]);
+        }
+    mx = rows_max(mx);
+    const float off = -mx * c2;                  // softmax(scale*s) = 2^(c2*s - c2*max) / sum
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c2, off));   // 2^(-inf) = 0 for masked keys
+}
+
+// O^T = V^T . P^T and the row sums; returns 1 / sum of this lane's query.  V^T fragments (two transposed reads per MFMA)
+// are requested a key-tile pair ahead of their MFMAs.
+template <typename T, int NT>
+__device__ __forceinline__ float tile_pv(const char* sV, const f32x4 (&s)[NT], int g, int li, f32x4 (&o)[4]) {
+    typedef typename Half16<T>::v8 v8;
+    constexpr int NP = (NT + 1) / 2;               // key-tile pairs of the second product (K = 32 per MFMA)
+    const int vr = li >> 2;                        // lane li of group g addresses row r0 + (li>>2), bytes (li&3)*8 of the d-tile
+    f32x4 osum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    v8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+    v8 vf[2][4];
+    auto read_v = [&](int s2, v8 (&dst)[4]) {
+        const bool has_hi = 2 * s2 + 1 < NT;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int rlo = 32 * s2 + 4 * g + vr, rhi = rlo + 16;
+            const int cl = dt * 2 + ((li & 3) >> 1), sub = (li & 1) * 8;
+            union { struct { s16x4 a, b; } h; v8 v; } u;
+            u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(sV + rlo * 128 + (v_swz(rlo, cl) << 4) + sub));
+            u.h.b = (s16x4){0, 0, 0, 0};
+            if (has_hi)
+                u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sV + rhi * 128 + (v_swz(rhi, cl) << 4) + sub));
+            dst[dt] = u.v;
+        }
+    };
+    read_v(0, vf[0]);
+#pragma unroll
+    for (int s2 = 0; s2 < NP; ++s2) {
+        constexpr T zero = (T)0.0f;
+        const bool has_hi = 2 * s2 + 1 < NT;
+        if (s2 + 1 < NP) read_v(s2 + 1, vf[(s2 + 1) & 1]);
+        v8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf[r] = Half16<T>::from_unit(s[2 * s2][r]);
+            pf[4 + r] = has_hi ? Half16<T>::from_unit(s[has_hi ? 2 * s2 + 1 : 0][r]) : zero;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = Half16<T>::mfma32(vf[s2 & 1][dt], pf, o[dt]);
+        osum = Half16<T>::mfma32(ones, pf, osum);          // every accumulator row = sum over this pair's 32 keys, per query (lane)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return __builtin_amdgcn_rcpf(osum[0]);
+}
+
+// (a convex combination of 16-bit values: no saturation needed on the way back to 16 bits)
+template <typename T>
+__device__ __forceinline__ void tile_store(T* row_out, const f32x4 (&o)[4], float inv, int g) {
+    typedef typename Half16<T>::v4 v4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        v4 ob;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[r] = (T)(o[dt][r] * inv);
+        *(v4*)(row_out + dt * 16 + g * 4) = ob;
+    }
+}
+
+// One workgroup per (sequence, head): any length up to 592, optional causal mask.
 template <typename T, int NT, int LS, int NW>      // NW waves per workgroup share the query tiles
 __global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 v8;
-    typedef typename Half16<T>::v4 v4;
     const T* qkv = (const T*)p.qkv;
     T* outp = (T*)p.out;
     constexpr int LK = NT * 16;
-    constexpr int NP = (NT + 1) / 2;               // key-tile pairs of the second product (K = 32 per MFMA)
     char* sK = smem;
     char* sV = smem + LK * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,134 +203,22 @@ __global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
     // K fragment read: row kt*16 + li, logical chunk ks*4 + g
     const int k_row_off = li * 128;
     const int k_sw = (li >> 1) & 7;
-    // V transposed read: lane li of group g addresses row r0 + (li>>2), bytes (li&3)*8 of the d-tile
-    const int vr = li >> 2;
-    const float c2 = p.scale * 1.44269504088896341f;     // softmax(scale*s) = 2^(c2*s - c2*max) / sum
+    const float c2 = p.scale * 1.44269504088896341f;
 
     for (int qt = wslot; qt < NT; qt += NW) {
         const int q = qt * 16 + li;                // this lane's query
-        // Every key tile is computed, also rows past L: a wave-uniform skip here would put a branch between an
-        // MFMA and the first read of its accumulator.
         // The K fragments do not depend on the query tile; left alone the compiler keeps all of them in registers
         // across the loop (2*NT*4 = 136 VGPRs), which leaves too few to keep the V^T reads of the second product in
         // flight.  An opaque copy of the row offset keeps the (cheap) LDS reads inside the loop.
         int k_row = k_row_off;
         asm volatile("" : "+v"(k_row));
-        // A wave issues in order and has at most one partner wave on its SIMD, so LDS latency is hidden by hand: the K
-        // fragments of the next batch of key tiles are requested before the MFMAs of the current batch are issued.
         f32x4 s[NT];
-        {
-            constexpr int KB = 4, NB = (NT + KB - 1) / KB;
-            v8 kf[2][KB][2];
-            auto read_k = [&](int b, v8 (&dst)[KB][2]) {
-#pragma unroll
-                for (int i = 0; i < KB; ++i)
-                    if (b * KB + i < NT) {
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks)
-                            dst[i][ks] = *(const v8*)(sK + (b * KB + i) * 2048 + k_row + (((ks * 4 + g) ^ k_sw) << 4));
-                    }
-            };
-            read_k(0, kf[0]);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (b + 1 < NB) read_k(b + 1, kf[(b + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < KB; ++i)
-                    if (b * KB + i < NT) {
-                        const int kt = b * KB + i;
-                        s[kt] = Half16<T>::mfma32(kf[b & 1][i][0], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f});
-                    }
-#pragma unroll
-                for (int i = 0; i < KB; ++i)
-                    if (b * KB + i < NT) {
-                        const int kt = b * KB + i;
-                        s[kt] = Half16<T>::mfma32(kf[b & 1][i][1], qf[1], s[kt]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        tile_scores<T, NT>(sK, k_row, k_sw, g, qf, s);
         if (qt + NW < NT) load_q(qt + NW, qf);      // lands while the softmax runs
-
-        // ---- mask + softmax over keys (per lane: one query).  Key kt*16 + 4g + r is valid iff kt*16 + r < lim. ----
-        const int lim = (causal ? min(L, q + 1) : L) - 4 * g;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool known_valid = LS && (kt * 16 + 15 < LS);      // every lane's key of this tile is < L
-                if (!known_valid) s[kt][r] = (kt * 16 + r < lim) ? s[kt][r] : -INFINITY;
-                mx = fmaxf(mx, s[kt][r]);
-            }
-        mx = rows_max(mx);
-        // two scores per instruction where the ISA has packed fp32 forms (v_pk_fma_f32, v_pk_add_f32); the exponential is scalar
-        const f32x2 c2v = {c2, c2}, offv = {-mx * c2, -mx * c2};
-        f32x2 sum2 = {0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const f32x2 x = __builtin_elementwise_fma((f32x2){s[kt][r], s[kt][r + 1]}, c2v, offv);
-                const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};   // 2^(-inf) = 0 for masked keys
-                s[kt][r] = e[0];
-                s[kt][r + 1] = e[1];
-                sum2 += e;
-            }
-        float sum = rows_sum(sum2[0] + sum2[1]);
-        const float inv = 1.0f / sum;
-
-        // ---- O^T = V^T . P^T ----
+        tile_softmax<NT, LS>(s, (causal ? min(L, q + 1) : L) - 4 * g, c2);
         f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        {
-            // V^T fragments (two transposed reads per MFMA) are requested a key-tile pair ahead of their MFMAs
-            v8 vf[2][4];
-            auto read_v = [&](int s2, v8 (&dst)[4]) {
-                const bool has_hi = 2 * s2 + 1 < NT;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int rlo = 32 * s2 + 4 * g + vr, rhi = rlo + 16;
-                    const int cl = dt * 2 + ((li & 3) >> 1), sub = (li & 1) * 8;
-                    union { struct { s16x4 a, b; } h; v8 v; } u;
-                    u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(sV + rlo * 128 + (v_swz(rlo, cl) << 4) + sub));
-                    u.h.b = (s16x4){0, 0, 0, 0};
-                    if (has_hi)
-                        u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(sV + rhi * 128 + (v_swz(rhi, cl) << 4) + sub));
-                    dst[dt] = u.v;
-                }
-            };
-            read_v(0, vf[0]);
-#pragma unroll
-            for (int s2 = 0; s2 < NP; ++s2) {
-                constexpr T zero = (T)0.0f;
-                const bool has_hi = 2 * s2 + 1 < NT;
-                if (s2 + 1 < NP) read_v(s2 + 1, vf[(s2 + 1) & 1]);
-                v8 pf;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pf[r] = Half16<T>::from_unit(s[2 * s2][r]);
-                    pf[4 + r] = has_hi ? Half16<T>::from_unit(s[has_hi ? 2 * s2 + 1 : 0][r]) : zero;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o[dt] = Half16<T>::mfma32(vf[s2 & 1][dt], pf, o[dt]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (q < L) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                v4 ob;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ob[r] = Half16<T>::from(o[dt][r] * inv);
-                *(v4*)(outp + (row0 + q) * p.ldo + h * 64 + dt * 16 + g * 4) = ob;
-            }
-        }
+        const float inv = tile_pv<T, NT>(sV, s, g, li, o);
+        if (q < L) tile_store<T>(outp + (row0 + q) * p.ldo + h * 64, o, inv, g);
     }
 }
 

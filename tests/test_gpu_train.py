@@ -234,8 +234,12 @@ def test_tail_gradients_match_reference_and_oracle(dev, golden, case):
         assert rg is not None, name
         err, ref_norm = (p.grad.cpu() - rg).norm().item(), rg.norm().item()
         # 2 % of the tensor's gradient norm (the towers feed fp16-rounded features into the tail) plus an absolute floor
-        # for gradients that are zero in exact arithmetic (key biases: softmax is shift invariant)
-        assert err <= 2e-2 * ref_norm + 1e-6, f"{name}: gradient error {err:.3e} vs norm {ref_norm:.3e}"
+        # for gradients that are zero in exact arithmetic (key biases: softmax is shift invariant).  The two temperature
+        # scalars get 6 %: each is ONE number, a difference of softmax weights summed over every patch, so it carries the
+        # towers' rounding noise undiluted (0.4 - 5 % from one rounding-order change of the attention kernel to the next;
+        # every other tensor stays below 1 %)
+        tol = 6e-2 if name.endswith(".temperature") else 2e-2
+        assert err <= tol * ref_norm + 1e-6, f"{name}: gradient error {err:.3e} vs norm {ref_norm:.3e}"
         if ref_norm > 1e-5:
             worst = max(worst, err / ref_norm)
         checked += 1

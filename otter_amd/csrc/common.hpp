@@ -59,10 +59,20 @@ enum { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
 
 // 16-bit MFMA operand types.  bf16 keeps fp32's range; fp16 carries 3 more mantissa bits at the same MFMA rate
 // (CLIP's published weights are fp16).  Conversions to fp16 saturate instead of overflowing to infinity.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// MODE.FP16_OVFL (bit 23 of the wave's MODE register): a result that overflows fp16 -- arithmetic or a conversion from fp32 --
+// is clamped to +-65504 instead of becoming an infinity (true infinities stay).  Set once at kernel entry, it makes every
+// fp32 -> fp16 conversion of the kernel saturate without the two-instruction clamp in front of it.
+__device__ __forceinline__ void fp16_saturate_on_overflow() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }
+
 template <typename T> struct Half16;
 template <> struct Half16<__bf16> {
     typedef bf16x8 v8;
     typedef bf16x4 v4;
+    typedef bf16x2 v2;
+    // two fp32 -> one packed pair (bf16 keeps fp32's range: nothing to saturate)
+    static __device__ __forceinline__ bf16x2 pack_sat_hw(float a, float b) { return (bf16x2){(__bf16)a, (__bf16)b}; }
     static __device__ __forceinline__ __bf16 from(float v) { return (__bf16)v; }
     static __device__ __forceinline__ __bf16 from_unit(float v) { return (__bf16)v; }      // v in [0, 1]
     static __device__ __forceinline__ f32x4 mfma32(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
@@ -72,6 +82,9 @@ template <> struct Half16<__bf16> {
 template <> struct Half16<_Float16> {
     typedef f16x8 v8;
     typedef f16x4 v4;
+    typedef f16x2 v2;
+    // two fp32 -> one packed pair, round to nearest even; saturating only in a kernel that called fp16_saturate_on_overflow()
+    static __device__ __forceinline__ f16x2 pack_sat_hw(float a, float b) { return (f16x2){(_Float16)a, (_Float16)b}; }
     static __device__ __forceinline__ _Float16 from(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
     static __device__ __forceinline__ _Float16 from_unit(float v) { return (_Float16)v; }  // v in [0, 1]: no saturation needed
     static __device__ __forceinline__ f32x4 mfma32(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     typedef typename Half16<T>::v8 frag_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
+    const int wr_u = __builtin_amdgcn_readfirstlane(wr), wc_u = __builtin_amdgcn_readfirstlane(wc);   // the same, known to be wave-uniform
     const int g = lane >> 4, li = lane & 15;
+    fp16_saturate_on_overflow();
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int nkt = p.K / 64;
@@ -329,19 +331,34 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                 }
         }
     } else
-    // lane (g, li): rows 16mt + 4g + r, columns 4li + 0..3 of the wave's 64
+    // lane (g, li): rows 16mt + 4g + r, columns 4li + 0..3 of the wave's 64.
+    // Every address is a wave-uniform 64-bit part (tile origin, wave block, row: scalar registers and scalar arithmetic)
+    // plus a 32-bit per-lane byte offset that never changes (4g rows, 4li columns), so a store or load costs no vector
+    // instruction for its address; the element arithmetic is written per scalar so that the accumulators are consumed
+    // where they sit (no register shuffles to build vectors) and the 16-bit conversion saturates in hardware (mode bit
+    // set at kernel entry).  The vector ALU, shared with the partner wave, sets the pace of this part of a tile.
     {
-        const int n = cn0 + wc * 64 + 4 * li;
+        const int n_u = cn0 + wc_u * 64;
+        const int n = n_u + 4 * li;
         if (n < p.N) {
+            constexpr int EO = OUT_F32 ? 4 : 2;                    // bytes per output element
+            typedef typename Half16<T>::v4 h4;
+            typedef typename Half16<T>::v2 h2;
+            const unsigned lane_c = (unsigned)(4 * g) * (unsigned)(p.ldc * EO) + (unsigned)(4 * li * EO);
+            const unsigned lane_r = (unsigned)(4 * g) * (unsigned)(p.ldr * EO) + (unsigned)(4 * li * EO);
+            const unsigned lane_s = (unsigned)(4 * g) * 8u;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = bv;
             if (p.bias) bv = *(const f32x4*)(p.bias + n);
             if (LNF) cs = *(const f32x4*)(p.ln_colsum + n);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
+                const int row_u = cm0 + wr_u * 128 + s * 64;                            // wave-uniform
+                char* c_u = (char*)p.C + ((long)row_u * p.ldc + n_u) * EO;
+                const char* r_u = RES ? (const char*)p.residual + ((long)row_u * p.ldr + n_u) * EO : nullptr;
+                const char* s_u = LNF ? (const char*)(p.ln_stats + 2 * (long)row_u) : nullptr;
                 // The residual is usually the output buffer itself, so the compiler must keep every load ahead of the next
                 // store and, loads and stores retiring in order, would wait out one memory round trip per row: fetch the
                 // residual of 16 rows first, then store the 16 rows.
-                typedef typename Half16<T>::v4 h4;
                 f32x4 rf[RES && OUT_F32 ? 16 : 1];
                 h4 rh[RES && !OUT_F32 ? 16 : 1];
                 f32x2 st[LNF ? 16 : 1];         // (mean, rstd) of the 16 rows, fetched ahead of the stores for the same reason
@@ -349,44 +366,41 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            st[mt * 4 + r] = *(const f32x2*)(p.ln_stats + 2 * (long)(cm0 + wr * 128 + s * 64 + mt * 16 + 4 * g + r));
+                        for (int r = 0; r < 4; ++r) st[mt * 4 + r] = *(const f32x2*)(s_u + (mt * 16 + r) * 8 + lane_s);
                 }
                 if (RES) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const long off = (long)(cm0 + wr * 128 + s * 64 + mt * 16 + 4 * g + r) * p.ldr + n;
-                            if constexpr (OUT_F32) rf[mt * 4 + r] = *(const f32x4*)((const float*)p.residual + off);
-                            else rh[mt * 4 + r] = *(const h4*)((const T*)p.residual + off);
+                            const char* src = r_u + (long)(mt * 16 + r) * (p.ldr * EO) + lane_r;
+                            if constexpr (OUT_F32) rf[mt * 4 + r] = *(const f32x4*)src;
+                            else rh[mt * 4 + r] = *(const h4*)src;
                         }
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int m = cm0 + wr * 128 + s * 64 + mt * 16 + 4 * g + r;
-                        f32x4 v = (f32x4){acc[s][0][mt][0][r], acc[s][0][mt][1][r], acc[s][1][mt][0][r], acc[s][1][mt][1][r]};
-                        if (LNF) v = (v - st[mt * 4 + r][0] * cs) * st[mt * 4 + r][1];
-                        v += bv;
+                        float v[4] = {acc[s][0][mt][0][r], acc[s][0][mt][1][r], acc[s][1][mt][0][r], acc[s][1][mt][1][r]};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act256<ACT>(v[e]);
-                        if (RES) {
-                            if constexpr (OUT_F32) {
-                                v += rf[mt * 4 + r];
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)rh[mt * 4 + r][e];
+                        for (int e = 0; e < 4; ++e) {
+                            if (LNF) v[e] = __builtin_fmaf(__builtin_fmaf(-st[mt * 4 + r][0], cs[e], v[e]), st[mt * 4 + r][1], bv[e]);
+                            else v[e] += bv[e];
+                            v[e] = act256<ACT>(v[e]);
+                            if (RES) {
+                                if constexpr (OUT_F32) v[e] += rf[mt * 4 + r][e];
+                                else v[e] += (float)rh[mt * 4 + r][e];
                             }
                         }
+                        char* dst = c_u + (long)(mt * 16 + r) * (p.ldc * EO) + lane_c;
                         if constexpr (OUT_F32) {
-                            *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
+                            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
                         } else {
-                            h4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = Half16<T>::from(v[e]);
-                            *(h4*)((T*)p.C + (long)m * p.ldc + n) = o;
+                            union { h2 h[2]; h4 q; } o;
+                            o.h[0] = Half16<T>::pack_sat_hw(v[0], v[1]);
+                            o.h[1] = Half16<T>::pack_sat_hw(v[2], v[3]);
+                            *(h4*)dst = o.q;
                         }
                     }
             }

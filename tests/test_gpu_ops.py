@@ -117,6 +117,31 @@ def test_gemm_residual_in_operand_type(dev, m, n, k, dtype):
         ops.gemm(a, wp, n, bias, residual=x.to(torch.float16 if dt == torch.bfloat16 else torch.bfloat16))
 
 
+@pytest.mark.parametrize("m,n,k", [(32768 // 4, 1024, 64), (300, 256, 128), (70, 64, 64)])
+def test_gemm_fp16_output_saturates(dev, m, n, k):
+    """fp16 outputs beyond +-65504 clamp to the largest finite value (never an infinity) on all three kernels, with and
+    without the 16-bit residual; values inside the range are untouched by the clamp."""
+    from otter_amd import ops
+    a = torch.ones(m, k, device=dev, dtype=torch.float16)
+    w = torch.zeros(n, k)
+    w[:, 0] = torch.linspace(-1.0, 1.0, n)                          # a row's products sum to w[j, 0]
+    bias = torch.zeros(n)
+    bias[0::4], bias[1::4], bias[2::4] = 7.0e4, -7.0e4, 65504.0      # over, under, exactly the limit; the rest small
+    w, bias = w.to(dev), bias.to(dev)
+    wp = ops.pack_weight(w, torch.float16)
+    x = (_randn(35, m, n) * 4).to(dev).to(torch.float16)
+    for res in (None, x):
+        for kw in ({}, dict(force_tile_128=True)):
+            out = ops.gemm(a, wp, n, bias, residual=None if res is None else res.clone(), **kw)
+            ref = a.float() @ w.to(torch.float16).float().t() + bias + (0 if res is None else res.float())
+            want = ref.clamp(-65504.0, 65504.0).to(torch.float16)
+            assert torch.isfinite(out.float()).all()
+            assert int((ref.abs() > 65504).sum()) > m * n // 8       # the case really overflows
+            big = ref.abs() > 6.0e4
+            assert torch.equal(out[big], want[big])
+            torch.testing.assert_close(out.float(), want.float(), rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("m,n,k,act", [(32896 // 4, 1024, 1024, "none"), (300, 256, 128, "quickgelu"), (70, 64, 64, "none")])
 def test_gemm_with_folded_layernorm(dev, m, n, k, act, dtype):

@@ -35,7 +35,6 @@ extern "C" {
 #define OTTER_EPI_OUT_F32 4       /* write fp32 instead of the 16-bit operand type (always on for fp32 operands) */
 #define OTTER_EPI_RESIDUAL 8      /* out = acc + bias + residual; residual has the OUTPUT's type (fp32 with OUT_F32, else the operand type); ACT_NONE */
 #define OTTER_EPI_TILE_128 16     /* tuning knob: always use the 128x128-tile kernel (default picks 256x256 for big shapes) */
-#define OTTER_EPI_MFMA_32X32 32   /* measurement knob: the 256x256-tile kernel issues v_mfma_f32_32x32x16 instead of 16x16x32 (16-bit output only) */
 
 int otter_hip_abi_version(void);
 const char* otter_last_error(void);

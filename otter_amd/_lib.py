@@ -20,7 +20,6 @@ ACT_NONE, ACT_QUICKGELU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
 OUT_F32 = 4
 RESIDUAL = 8
 TILE_128 = 16
-MFMA_32X32 = 32
 
 
 class OtterHipError(RuntimeError):

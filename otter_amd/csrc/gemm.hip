@@ -27,7 +27,7 @@
 bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc);
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                          void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
-                         const float* ln_colsum, bool mf32, hipStream_t s);
+                         const float* ln_colsum, hipStream_t s);
 
 // 64x64-tile kernel for remainder rows and small problems (gemm_tail.hip)
 bool otter_gemm64_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc);
@@ -285,8 +285,7 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, int n_pa
         // Rows are independent: whole 256-row tiles go to the 256x256 kernel, the remaining (< 256) rows to the
         // 64x64 kernel.
         const int m_main = (M / 256) * 256;
-        int rc = otter_gemm256_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, m_main, N, K, act, out_f32, res, ln_stats, ln_colsum,
-                                      (epilogue & OTTER_EPI_MFMA_32X32) != 0, s);
+        int rc = otter_gemm256_launch(dtype, A, lda, W, bias, residual, ldr, C, ldc, m_main, N, K, act, out_f32, res, ln_stats, ln_colsum, s);
         if (rc != OTTER_OK || m_main == M) return rc;
         const long ec = (out_f32 ? 4 : es);
         const int rem = M - m_main;

@@ -10,21 +10,29 @@
 //
 // Data movement.  Each operand tile of a K-step is cut into two 16 KiB "half-tiles" (128 rows x 128 bytes):
 //   A_h0 = tile rows {0..63, 128..191}   A_h1 = tile rows {64..127, 192..255}
-//   B_h0, B_h1 = the two 32-row halves of every wave column's 64 weight rows (which output columns those are: set_tile)
+//   B_h0, B_h1 = the two 32-row halves of every wave column's 64 weight rows (which output columns those are: a_th / w_th)
 // so that every wave's work splits into four quadrants (A_h0,B_h0) (A_h0,B_h1) (A_h1,B_h1) (A_h1,B_h0), 16 MFMAs each.
 // A K-step runs as two halves, one per A half-tile: a load segment (fragment reads of the A half -- and, in the
 // first half, of both B halves, which stay in registers -- plus LDS-DMA issues) and an MFMA segment of two quadrants,
 // separated by workgroup barriers (four per K-step).
 // LDS holds two K-steps x four half-tile slots (128 KiB).  Half-tiles arrive by LDS-DMA (global_load_lds_dwordx4,
 // two instructions per thread per half-tile) and a slot is refilled as soon as its last reader segment is over:
-//   first load segment of K-step t: A_h1(t+1)      second: A_h0(t+2), B_h0(t+2), B_h1(t+2)
+//   first load segment of K-step s: A_h1(s+1)      second: A_h0(s+2), B_h0(s+2), B_h1(s+2)
 // Every load therefore has more than a K-step (>= 2048 MFMA cycles) to land, and only ONE counted wait per K-step is
 // needed: s_waitcnt vmcnt(6) at the end of the K-step leaves the six youngest requests in flight and guarantees
-// that all of K-step t+1 has landed (the barrier that follows publishes it to the other waves).  The loop never
+// that all of K-step s+1 has landed (the barrier that follows publishes it to the other waves).  The loop never
 // drains the memory queue; raw s_barrier is used because __syncthreads() would add vmcnt(0).
+//
+// The K-steps of all the tiles a workgroup computes form ONE stream: s counts across tile boundaries, so the loads of
+// the next tile's first two K-steps are requested from the last two K-steps of the current tile (whose slots are free
+// by the same rule as inside a tile), land under its MFMAs and its epilogue, and the next tile's K-loop starts without a
+// prologue, a drain of the memory queue or a barrier of its own.  The epilogue's stores sit in the queue between the
+// loads of the two K-steps and are first waited for by the counted wait at the end of the next tile's first K-step.
 //
 // LDS images are lane-linear (LDS-DMA requirement) with the 16-byte chunk index XOR-swizzled on the source
 // address and on the ds_read_b128 address, as in gemm.hip.
+#include <type_traits>
+
 #include "common.hpp"
 #include "otter_hip.h"
 
@@ -58,75 +66,61 @@ template <int ACT> __device__ __forceinline__ float act256(float v) {
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// LNF: LayerNorm folded into the epilogue (p.ln_stats).  MF32: the K-loop issues v_mfma_f32_32x32x16 (2 x 1 tiles of
-// 32x32 per quadrant, four 16-element k-sub-steps) instead of v_mfma_f32_16x16x32 (4 x 2 tiles of 16x16, two 32-element
-// k-sub-steps): same LDS image, same fragment bytes, same accumulator count, half as many MFMA instructions.
-template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false, bool MF32 = false>
+// LNF: LayerNorm folded into the epilogue (p.ln_stats).
+template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false>
 __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 frag_t;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: everything derived from it is scalar
     const int wr = wave >> 2, wc = wave & 3;
-    const int wr_u = __builtin_amdgcn_readfirstlane(wr), wc_u = __builtin_amdgcn_readfirstlane(wc);   // the same, known to be wave-uniform
     const int g = lane >> 4, li = lane & 15;
     fp16_saturate_on_overflow();
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int nkt = p.K / 64;
-    int m0, n0;
-    unsigned a_off[2][2], w_off[2][2];      // LDS-DMA source offsets (bytes from A / W): [half][instruction]
-    // Tile `t` of the launch order -> (m0, n0) and the per-thread source offsets of its half-tiles.  The accumulator of
-    // an (m-tile, n-tile) pair holds C[16mt + 4g + r][column li of the n-tile] in register r of lane (g, li).  Image row
-    // (n-tile nt, i) of half x of a wave's 64 columns is given the weight row of column 4i + 2x + nt, so the four n-tiles
-    // of a lane are 4 CONSECUTIVE output columns: the 16 lanes of a group store one contiguous 128-byte (16-bit output) or
-    // 256-byte (fp32) piece of a row, every quad of lanes a contiguous part of it (stores whose quads touch four rows
-    // take four times as long in the address unit).
-    auto set_tile = [&](int t) {
+    // LDS-DMA source offsets of this thread inside a tile's row blocks (bytes from the tile's first A row / first weight
+    // row, K-step 0): [half][instruction].  They do not depend on the tile: a request's address is a scalar base (tile
+    // origin + K-step) plus one of these.
+    // The accumulator of an (m-tile, n-tile) pair holds C[16mt + 4g + r][column li of the n-tile] in register r of lane
+    // (g, li).  Image row (n-tile nt, i) of half x of a wave's 64 columns is given the weight row of column 4i + 2x + nt, so
+    // the four n-tiles of a lane are 4 CONSECUTIVE output columns: the 16 lanes of a group store one contiguous 128-byte
+    // (16-bit output) or 256-byte (fp32) piece of a row, every quad of lanes a contiguous part of it (stores whose quads
+    // touch four rows take four times as long in the address unit).
+    unsigned a_th[2][2], w_th[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = (wave * 2 + i) * 8 + (lane >> 3);            // local row inside the half-tile image
+        const int c = (lane & 7) ^ ((lr >> 1) & 7);
+        const int fi = lr & 15, fnt = (lr >> 4) & 1;
+        const int wcol = (lr >> 5) * 64 + 4 * fi + fnt;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int trow = (lr < 64 ? lr : lr + 64) + x * 64;      // A: tile row
+            a_th[x][i] = (unsigned)trow * (unsigned)(p.lda * 2) + c * 16;
+            w_th[x][i] = (unsigned)(wcol + x * 2) * (unsigned)(p.K * 2) + c * 16;
+        }
+    }
+    // Tile `t` of the launch order -> (m0, n0); scalar arithmetic
+    auto tile_origin = [&](int t, int& m0, int& n0) {
         const int pid = xcd_remap(t, nwg);
         const int width = GROUP_M256 * p.tiles_n;
         const int first_m = (pid / width) * GROUP_M256;
         const int gsz = min(p.tiles_m - first_m, GROUP_M256);
         m0 = (first_m + (pid % width) % gsz) * TM;
         n0 = ((pid % width) / gsz) * TN;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int lr = (wave * 2 + i) * 8 + (lane >> 3);            // local row inside the half-tile image
-            const int c = (lane & 7) ^ ((lr >> 1) & 7);
-            const int fi = lr & 15, fnt = (lr >> 4) & 1;
-            // MF32: image row c = lr & 31 of half x is lane c's column in the 32x32 tile; it gets weight row 2c + x, so a
-            // lane's two accumulators of an output row are 2 consecutive columns
-            const int wcol = MF32 ? (lr >> 5) * 64 + 2 * (lr & 31) : (lr >> 5) * 64 + 4 * fi + fnt;
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const int trow = (lr < 64 ? lr : lr + 64) + x * 64;      // A: tile row
-                a_off[x][i] = (unsigned)(m0 + trow) * (unsigned)(p.lda * 2) + c * 16;
-                w_off[x][i] = (unsigned)(n0 + wcol + x * (MF32 ? 1 : 2)) * (unsigned)(p.K * 2) + c * 16;
-            }
-        }
     };
-    auto issue = [&](int buf, int slot, int kt) {
+    // (32-bit offsets from A and W: the request's address is a scalar 64-bit base plus a 32-bit per-lane offset)
+    auto issue = [&](int buf, int slot, unsigned a_base, unsigned w_base) {
         char* dst = smem + (buf * 4 + slot) * HALF_BYTES + wave * 2048;
-        const unsigned kb = (unsigned)kt * 128u;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const char* src;
-            if (slot == SLOT_A0) src = p.A + (a_off[0][i] + kb);
-            else if (slot == SLOT_A1) src = p.A + (a_off[1][i] + kb);
-            else if (slot == SLOT_B0) src = p.W + (w_off[0][i] + kb);
-            else src = p.W + (w_off[1][i] + kb);
+            if (slot == SLOT_A0) src = p.A + (a_base + a_th[0][i]);
+            else if (slot == SLOT_A1) src = p.A + (a_base + a_th[1][i]);
+            else if (slot == SLOT_B0) src = p.W + (w_base + w_th[0][i]);
+            else src = p.W + (w_base + w_th[1][i]);
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + i * 1024), 16, 0, 0);
-        }
-    };
-    // K-step 0 completely, plus the three half-tiles of K-step 1 that the second half of K-step -1 would issue
-    auto issue_prologue = [&]() {
-        issue(0, SLOT_A0, 0);
-        issue(0, SLOT_B0, 0);
-        issue(0, SLOT_B1, 0);
-        issue(0, SLOT_A1, 0);
-        if (nkt > 1) {
-            issue(1, SLOT_A0, 1);
-            issue(1, SLOT_B0, 1);
-            issue(1, SLOT_B1, 1);
         }
     };
 
@@ -135,101 +129,89 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     int koff[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) koff[ks] = li * 128 + (((ks * 4 + g) ^ swz) << 4);
-    // MF32: lane (h = lane >> 5, r = lane & 31) reads row r of a 32-row tile, 16-byte chunk 2*ks + h of its 128 bytes
-    int koff32[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff32[ks] = (lane & 31) * 128 + (((ks * 2 + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
     const int a_row0 = wr * 64 * 128;          // this wave's 64 rows inside an A half-tile
     const int b_row0 = wc * 32 * 128;          // this wave's 32 rows inside a B half-tile
 
     f32x4 acc[2][2][4][2];                      // [A half s][B half x][m-tile][n-tile]
-    f32x16 acc32[2][2][2];                      // MF32: [A half s][B half x][32-row m-tile]
-    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    const bool late = wave >= 4;
 
-    // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The next tile's prologue loads are
-    // issued before the current tile's epilogue stores, so they land while the stores drain.
-    int tile = blockIdx.x;
-    set_tile(tile);
-    issue_prologue();
-    bool first = true;
-    while (true) {
-        const int cm0 = m0, cn0 = n0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[s][x][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (MF32) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) acc32[s][x][mt][j] = 0.f;
+    // ---- the load stream (wave-uniform state).  Cursor 2 = the K-step two ahead of the one being computed (its A_h0,
+    // B_h0, B_h1 are requested next), cursor 1 = the K-step one ahead (its A_h1 is requested next). ----
+    int tile = blockIdx.x;                      // the tile being computed
+    int cm0, cn0;
+    tile_origin(tile, cm0, cn0);
+    int s_tile = tile, s_k = 0;
+    unsigned a2 = (unsigned)cm0 * (unsigned)(p.lda * 2);         // byte offsets of the K-step's first A row / weight row
+    unsigned w2 = (unsigned)cn0 * (unsigned)(p.K * 2);
+    bool ok2 = true;
+    auto advance2 = [&]() {
+        if (++s_k < nkt) {
+            a2 += 128;
+            w2 += 128;
+        } else {
+            s_k = 0;
+            s_tile += gridDim.x;
+            ok2 = s_tile < nwg;
+            if (ok2) {
+                int m0, n0;
+                tile_origin(s_tile, m0, n0);
+                a2 = (unsigned)m0 * (unsigned)(p.lda * 2);
+                w2 = (unsigned)n0 * (unsigned)(p.K * 2);
+            }
+        }
+    };
+    // K-step 0 completely, plus the three half-tiles of K-step 1 that the second half of K-step -1 would request
+    issue(0, SLOT_A0, a2, w2);
+    issue(0, SLOT_B0, a2, w2);
+    issue(0, SLOT_B1, a2, w2);
+    issue(0, SLOT_A1, a2, w2);
+    advance2();
+    unsigned a1 = a2;
+    bool ok1 = ok2;
+    if (ok2) {
+        issue(1, SLOT_A0, a2, w2);
+        issue(1, SLOT_B0, a2, w2);
+        issue(1, SLOT_B1, a2, w2);
     }
-    // first tile: the two youngest half-tiles may stay in flight; later tiles: the epilogue's stores were issued
-    // after the prologue loads, so everything is drained
-    if (first && nkt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    advance2();
+    if (ok1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    first = false;
     wg_barrier();
 
     frag_t af[4][2], bf[2][2][2];               // A half in use; both B halves of the K-step: [half x][n-tile][k-sub-step]
-    // (MF32 keeps the same register arrays: af[2*mt2 + (ks >> 1)][ks & 1] is fragment (32-row tile mt2, k-sub-step ks),
-    //  bf[x][ks >> 1][ks & 1] fragment (half x, k-sub-step ks))
     auto load_a = [&](int buf, int slot) {
         const char* base = smem + (buf * 4 + slot) * HALF_BYTES + a_row0;
-        if constexpr (MF32) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) af[2 * mt + (ks >> 1)][ks & 1] = *(const frag_t*)(base + mt * 4096 + koff32[ks]);
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const frag_t*)(base + mt * 2048 + koff[ks]);
-        }
+            for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const frag_t*)(base + mt * 2048 + koff[ks]);
     };
     auto load_b = [&](int buf, int slot, int x) {
         const char* base = smem + (buf * 4 + slot) * HALF_BYTES + b_row0;
-        if constexpr (MF32) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) bf[x][ks >> 1][ks & 1] = *(const frag_t*)(base + koff32[ks]);
-        } else {
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) bf[x][nt][ks] = *(const frag_t*)(base + nt * 2048 + koff[ks]);
-        }
+            for (int ks = 0; ks < 2; ++ks) bf[x][nt][ks] = *(const frag_t*)(base + nt * 2048 + koff[ks]);
     };
+    // a tile's first K-step starts its accumulators from the constant 0 (no zero-fill pass over 128 registers)
 #define OTTER_QUADRANT(S, X)                                                                              \
-    if constexpr (MF32) {                                                                                 \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                   \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                               \
-                acc32[S][X][mt] = Half16<T>::mfma32x32(af[2 * mt + (ks >> 1)][ks & 1], bf[X][ks >> 1][ks & 1], acc32[S][X][mt]); \
-    } else {                                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                   \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                               \
-                acc[S][X][mt][nt] = Half16<T>::mfma32(af[mt][ks], bf[X][nt][ks], acc[S][X][mt][nt]);       \
-    }
+                acc[S][X][mt][nt] = Half16<T>::mfma32(af[mt][ks], bf[X][nt][ks],                           \
+                                                      (FIRST && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[S][X][mt][nt]);
 
-    // A K-step is two halves, one per A half-tile: load segment (fragment reads + LDS-DMA issues) then MFMA segment (two
+    // A K-step is two halves, one per A half-tile: load segment (fragment reads + LDS-DMA requests) then MFMA segment (two
     // quadrants = 32 MFMAs per wave), four workgroup barriers per K-step.  Both B halves are read in the first half
     // and stay in registers for the second.
     // Two wave groups (waves 0-3 / 4-7; each SIMD hosts one wave of each) run the same program one barrier apart:
     // while one group is in a load segment the other is in its MFMA segment, so the matrix pipe of every SIMD always has
-    // a wave feeding it.  Group 1 starts one barrier late and group 0 ends with one extra barrier.
+    // a wave feeding it.  Group 1 starts one barrier late (once, ahead of the first tile) and group 0 ends with one extra
+    // barrier (after the last tile).
     // Slot refills (write after read): A_h0, B_h0, B_h1 of a buffer are last read in the first load segment, so their
-    // K-step t+2 contents are requested in the second one; A_h1 is last read in the second and refilled in the first
-    // load segment of K-step t+1.  K-step t+1 is therefore complete once at most the six requests of the second load
-    // segment of K-step t are outstanding: one counted wait per K-step, at the end of the same global segment for
+    // K-step s+2 contents are requested in the second one; A_h1 is last read in the second and refilled in the first
+    // load segment of K-step s+1.  K-step s+1 is therefore complete once at most the six requests of the second load
+    // segment of K-step s are outstanding: one counted wait per K-step, at the end of the same global segment for
     // both groups, one barrier before the first reader.
 #define OTTER_SEG_END()                                     \
     __builtin_amdgcn_sched_barrier(0);                      \
@@ -241,27 +223,27 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     OTTER_QUADRANT(S, X1)                                   \
     __builtin_amdgcn_s_setprio(0);
 #define OTTER_RETIRE_NEXT()                                                       \
-    if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");             \
+    if (ok2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    if (late) { OTTER_SEG_END() }
-    for (int t = 0; t < nkt; ++t) {
-        const int buf = t & 1;
+    int buf = 0;                                // LDS buffer of the K-step being computed (stream parity)
+    auto k_step = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         // first half: (A_h0, B_h0), (A_h0, B_h1)
         load_a(buf, SLOT_A0);
         load_b(buf, SLOT_B0, 0);
         load_b(buf, SLOT_B1, 1);
-        if (t + 1 < nkt) issue(buf ^ 1, SLOT_A1, t + 1);
+        if (ok1) issue(buf ^ 1, SLOT_A1, a1, w2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         OTTER_SEG_END()
         OTTER_MFMA_SEG2(0, 0, 1)
         OTTER_SEG_END()
         // second half: (A_h1, B_h1), (A_h1, B_h0)
         load_a(buf, SLOT_A1);
-        if (t + 2 < nkt) {
-            issue(buf, SLOT_A0, t + 2);
-            issue(buf, SLOT_B0, t + 2);
-            issue(buf, SLOT_B1, t + 2);
+        if (ok2) {
+            issue(buf, SLOT_A0, a2, w2);
+            issue(buf, SLOT_B0, a2, w2);
+            issue(buf, SLOT_B1, a2, w2);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (late) { OTTER_RETIRE_NEXT() }
@@ -269,68 +251,18 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
         OTTER_MFMA_SEG2(1, 1, 0)
         if (!late) { OTTER_RETIRE_NEXT() }
         OTTER_SEG_END()
-    }
-    if (!late) { OTTER_SEG_END() }
+        a1 = a2;
+        ok1 = ok2;
+        advance2();
+        buf ^= 1;
+    };
 
-    // ---- all LDS reads of this tile are complete (every load segment ends with lgkmcnt(0) before its barrier):
-    //      start the next tile's loads, then store this one ----
-    tile += gridDim.x;
-    const bool more = tile < nwg;
-    if (more) {
-        set_tile(tile);
-        issue_prologue();
-    }
-    if constexpr (MF32) {
-        // lane (h, c): rows 32mt + 8(j >> 2) + 4h + (j & 3) of each 64-row half, columns 2c + 0..1 of the wave's 64
-        const int h = lane >> 5, c = lane & 31;
-        const int n = cn0 + wc * 64 + 2 * c;
-        if (n < p.N) {
-            f32x2 bv = {0.f, 0.f}, cs = bv;
-            if (p.bias) bv = *(const f32x2*)(p.bias + n);
-            if (LNF) cs = *(const f32x2*)(p.ln_colsum + n);
-            typedef __attribute__((ext_vector_type(2))) T h2;
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    f32x2 rf[RES && OUT_F32 ? 16 : 1];
-                    h2 rh[RES && !OUT_F32 ? 16 : 1];
-                    f32x2 st[LNF ? 16 : 1];
-                    const int mbase = cm0 + wr * 128 + s * 64 + mt * 32 + 4 * h;
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int m = mbase + 8 * (j >> 2) + (j & 3);
-                        if (LNF) st[j] = *(const f32x2*)(p.ln_stats + 2 * (long)m);
-                        if (RES) {
-                            const long off = (long)m * p.ldr + n;
-                            if constexpr (OUT_F32) rf[j] = *(const f32x2*)((const float*)p.residual + off);
-                            else rh[j] = *(const h2*)((const T*)p.residual + off);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int m = mbase + 8 * (j >> 2) + (j & 3);
-                        f32x2 v = (f32x2){acc32[s][0][mt][j], acc32[s][1][mt][j]};
-                        if (LNF) v = (v - st[j][0] * cs) * st[j][1];
-                        v += bv;
-                        v[0] = act256<ACT>(v[0]);
-                        v[1] = act256<ACT>(v[1]);
-                        if (RES) {
-                            if constexpr (OUT_F32) v += rf[j];
-                            else { v[0] += (float)rh[j][0]; v[1] += (float)rh[j][1]; }
-                        }
-                        if constexpr (OUT_F32) {
-                            *(f32x2*)((float*)p.C + (long)m * p.ldc + n) = v;
-                        } else {
-                            h2 o;
-                            o[0] = Half16<T>::from(v[0]);
-                            o[1] = Half16<T>::from(v[1]);
-                            *(h2*)((T*)p.C + (long)m * p.ldc + n) = o;
-                        }
-                    }
-                }
-        }
-    } else
+    if (late) { OTTER_SEG_END() }
+    while (true) {
+    k_step(std::true_type{});
+    for (int t = 1; t < nkt; ++t) k_step(std::false_type{});
+
+    // ---- store the tile (the next tile's first K-steps are landing meanwhile) ----
     // lane (g, li): rows 16mt + 4g + r, columns 4li + 0..3 of the wave's 64.
     // Every address is a wave-uniform 64-bit part (tile origin, wave block, row: scalar registers and scalar arithmetic)
     // plus a 32-bit per-lane byte offset that never changes (4g rows, 4li columns), so a store or load costs no vector
@@ -338,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     // where they sit (no register shuffles to build vectors) and the 16-bit conversion saturates in hardware (mode bit
     // set at kernel entry).  The vector ALU, shared with the partner wave, sets the pace of this part of a tile.
     {
-        const int n_u = cn0 + wc_u * 64;
+        const int n_u = cn0 + wc * 64;
         const int n = n_u + 4 * li;
         if (n < p.N) {
             constexpr int EO = OUT_F32 ? 4 : 2;                    // bytes per output element
@@ -352,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
             if (LNF) cs = *(const f32x4*)(p.ln_colsum + n);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int row_u = cm0 + wr_u * 128 + s * 64;                            // wave-uniform
+                const int row_u = cm0 + wr * 128 + s * 64;                              // wave-uniform
                 char* c_u = (char*)p.C + ((long)row_u * p.ldc + n_u) * EO;
                 const char* r_u = RES ? (const char*)p.residual + ((long)row_u * p.ldr + n_u) * EO : nullptr;
                 const char* s_u = LNF ? (const char*)(p.ln_stats + 2 * (long)row_u) : nullptr;
@@ -406,17 +338,20 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
             }
         }
     }
-    if (!more) break;
+    tile += gridDim.x;
+    if (tile >= nwg) break;
+    tile_origin(tile, cm0, cn0);
     }   // tile loop
+    if (!late) { OTTER_SEG_END() }
 #undef OTTER_SEG_END
 #undef OTTER_MFMA_SEG2
 #undef OTTER_RETIRE_NEXT
 #undef OTTER_QUADRANT
 }
 
-template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false, bool MF32 = false>
+template <typename T, int ACT, bool OUT_F32, bool RES, bool LNF = false>
 int launch256(const Gemm256Args& a, hipStream_t s) {
-    auto kern = gemm_256x256<T, ACT, OUT_F32, RES, LNF, MF32>;
+    auto kern = gemm_256x256<T, ACT, OUT_F32, RES, LNF>;
     if (int rc = otter_reserve_lds((const void*)kern, LDS_BYTES, "otter_gemm (256x256)")) return rc;
     const int n_cu = otter_cu_count("otter_gemm (256x256)");
     if (n_cu <= 0) return OTTER_ERR_LAUNCH;
@@ -427,17 +362,7 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
 }
 
 template <typename T>
-int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, bool mf32, hipStream_t s) {
-    if (mf32) {         // measurement variant: 16-bit output, the three epilogues of a CLIP block
-        if (out_f32) { otter_set_error("otter_gemm (256x256, 32x32x16): 16-bit output only"); return OTTER_ERR_UNSUPPORTED_SHAPE; }
-        if (res) return launch256<T, ACT_NONE, false, true, false, true>(a, s);
-        if (a.ln_stats) {
-            if (act == OTTER_EPI_ACT_NONE) return launch256<T, ACT_NONE, false, false, true, true>(a, s);
-            if (act == OTTER_EPI_ACT_QUICKGELU) return launch256<T, ACT_QUICKGELU, false, false, true, true>(a, s);
-        } else if (act == OTTER_EPI_ACT_NONE) return launch256<T, ACT_NONE, false, false, false, true>(a, s);
-        otter_set_error("otter_gemm (256x256, 32x32x16): epilogue not instantiated");
-        return OTTER_ERR_UNSUPPORTED_SHAPE;
-    }
+int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, hipStream_t s) {
     if (res) return out_f32 ? launch256<T, ACT_NONE, true, true>(a, s) : launch256<T, ACT_NONE, false, true>(a, s);
     if (a.ln_stats && !out_f32) {
         switch (act) {
@@ -471,11 +396,11 @@ bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K,
 
 int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                          void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
-                         const float* ln_colsum, bool mf32, hipStream_t s) {
+                         const float* ln_colsum, hipStream_t s) {
     if (M <= 0 || M % TM != 0) {                     // whole 256-row tiles only: the caller sends the remainder elsewhere
         otter_set_error("otter_gemm (256x256): M=%d is not a positive multiple of %d", M, TM);
         return OTTER_ERR_UNSUPPORTED_SHAPE;
     }
     Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, (N + TN - 1) / TN, ln_stats, ln_colsum};
-    return dtype == DT_BF16 ? dispatch256<__bf16>(a, act, out_f32, res, mf32, s) : dispatch256<_Float16>(a, act, out_f32, res, mf32, s);
+    return dtype == DT_BF16 ? dispatch256<__bf16>(a, act, out_f32, res, s) : dispatch256<_Float16>(a, act, out_f32, res, s);
 }

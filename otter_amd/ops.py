@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, DT_BF16, DT_F16, DT_F32, MFMA_32X32, OUT_F32, RESIDUAL, TILE_128,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, DT_BF16, DT_F16, DT_F32, OUT_F32, RESIDUAL, TILE_128,  # noqa: F401
                    OtterHipError, ReadoutBlock)
 
 Tensor = torch.Tensor
@@ -82,7 +82,6 @@ def pack_weight(w: Tensor, dtype=torch.bfloat16, device=None) -> Tensor:
 
 _GEMM_WS = {}
 _SPLIT_K = os.environ.get("OTTER_SPLIT_K", "1") != "0"       # tuning knob: 0 = never take the split-K path
-MFMA_32 = os.environ.get("OTTER_GEMM_MFMA32", "0") == "1"     # measurement knob: 32x32x16 MFMAs in the 256x256 kernel where instantiated
 
 
 _GEMM_WS_GUARD = threading.Lock()
@@ -150,8 +149,6 @@ def gemm(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor] = None, *, 
         raise ValueError(f"gemm.residual: {residual.dtype}, expected float32 or {a.dtype}")
     f32_out = out_f32 or (residual is not None and residual.dtype == torch.float32) or a.dtype == torch.float32
     epi = act | (OUT_F32 if f32_out else 0) | (RESIDUAL if residual is not None else 0) | (TILE_128 if force_tile_128 else 0)
-    if MFMA_32 and not f32_out and act in (ACT_NONE, ACT_QUICKGELU) and (act == ACT_NONE or ln_stats is not None):
-        epi |= MFMA_32X32
     odt = torch.float32 if f32_out else a.dtype
     if out is None:
         out = torch.empty(m, n, dtype=odt, device=a.device)

@@ -28,6 +28,9 @@
 // by the same rule as inside a tile), land under its MFMAs and its epilogue, and the next tile's K-loop starts without a
 // prologue, a drain of the memory queue or a barrier of its own.  The epilogue's stores sit in the queue between the
 // loads of the two K-steps and are first waited for by the counted wait at the end of the next tile's first K-step.
+// Every K-step makes the same eight requests, also the last two of the stream (which re-request the stream's last K-step
+// into slots nobody reads again): with the same number of requests on every path the counted waits -- the hand-written
+// ones and those the compiler places in front of the epilogue's operands -- never have to fall back to draining the queue.
 //
 // LDS images are lane-linear (LDS-DMA requirement) with the 16-byte chunk index XOR-swizzled on the source
 // address and on the ds_read_b128 address, as in gemm.hip.
@@ -40,7 +43,8 @@ namespace {
 
 constexpr int TM = 256, TN = 256;
 constexpr int HALF_BYTES = 128 * 128;             // one half-tile
-constexpr int LDS_BYTES = 2 * 4 * HALF_BYTES;     // 128 KiB
+constexpr int STAGE_BYTES = 2048;                 // per wave: epilogue operands staged through LDS (see stage_fetch)
+constexpr int LDS_BYTES = 2 * 4 * HALF_BYTES + 8 * STAGE_BYTES;     // 128 KiB of tiles + 16 KiB
 constexpr int GROUP_M256 = 4;
 
 struct Gemm256Args {
@@ -138,13 +142,16 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     // ---- the load stream (wave-uniform state).  Cursor 2 = the K-step two ahead of the one being computed (its A_h0,
     // B_h0, B_h1 are requested next), cursor 1 = the K-step one ahead (its A_h1 is requested next). ----
     int tile = blockIdx.x;                      // the tile being computed
-    int cm0, cn0;
+    int cm0, cn0;                               // its origin
     tile_origin(tile, cm0, cn0);
     int s_tile = tile, s_k = 0;
     unsigned a2 = (unsigned)cm0 * (unsigned)(p.lda * 2);         // byte offsets of the K-step's first A row / weight row
     unsigned w2 = (unsigned)cn0 * (unsigned)(p.K * 2);
     bool ok2 = true;
+    // (past the end of the stream the cursor stays on the last K-step it reached: requests keep being made -- see k_step --
+    //  and have to name memory that exists)
     auto advance2 = [&]() {
+        if (!ok2) return;
         if (++s_k < nkt) {
             a2 += 128;
             w2 += 128;
@@ -167,22 +174,18 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     issue(0, SLOT_A1, a2, w2);
     advance2();
     unsigned a1 = a2;
-    bool ok1 = ok2;
-    if (ok2) {
-        issue(1, SLOT_A0, a2, w2);
-        issue(1, SLOT_B0, a2, w2);
-        issue(1, SLOT_B1, a2, w2);
-    }
+    issue(1, SLOT_A0, a2, w2);
+    issue(1, SLOT_B0, a2, w2);
+    issue(1, SLOT_B1, a2, w2);
     advance2();
-    if (ok1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     wg_barrier();
 
     frag_t af[4][2], bf[2][2][2];               // A half in use; both B halves of the K-step: [half x][n-tile][k-sub-step]
-    auto load_a = [&](int buf, int slot) {
+    auto load_a = [&](int buf, int slot, int mt0, int mt1) {
         const char* base = smem + (buf * 4 + slot) * HALF_BYTES + a_row0;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = mt0; mt < mt1; ++mt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const frag_t*)(base + mt * 2048 + koff[ks]);
     };
@@ -222,29 +225,48 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     OTTER_QUADRANT(S, X0)                                   \
     OTTER_QUADRANT(S, X1)                                   \
     __builtin_amdgcn_s_setprio(0);
-#define OTTER_RETIRE_NEXT()                                                       \
-    if (ok2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define OTTER_RETIRE_NEXT() asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+
+    // ---- epilogue operands that come from memory.  Loaded into registers where they are used, each costs the epilogue a
+    // memory round trip behind the load stream's requests in flight (and the compiler, which cannot count requests across
+    // the tile loop, drains the whole queue in front of them).  The small ones -- bias and LayerNorm column sums of the
+    // wave's 64 columns, (mean, rstd) of its 128 rows -- are therefore requested from the tile's LAST K-step by LDS-DMA into
+    // a 2 KiB staging area of the wave's own (no registers held, complete at that K-step's counted wait, read back by
+    // ds_read in the epilogue):   [0, 1024) (mean, rstd) x 128 rows   [1024, 1280) bias x 64   [1280, 1536) column sums x 64
+    constexpr int EO = OUT_F32 ? 4 : 2;                    // bytes per output element
+    typedef typename Half16<T>::v4 h4;
+    typedef typename Half16<T>::v2 h2;
+    const unsigned lane_c = (unsigned)(4 * g) * (unsigned)(p.ldc * EO) + (unsigned)(4 * li * EO);
+    const unsigned lane_r = (unsigned)(4 * g) * (unsigned)(p.ldr * EO) + (unsigned)(4 * li * EO);
+    char* const stage = smem + 2 * 4 * HALF_BYTES + wave * STAGE_BYTES;
+    auto stage_fetch = [&]() {
+        const int n = cn0 + wc * 64 + lane;
+        const int n_ld = n < p.N ? n : cn0;                 // lanes beyond N: any column in bounds, never used
+        if (p.bias) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p.bias + n_ld), LDS_PTR(stage + 1024), 4, 0, 0);
+        if (LNF) {
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p.ln_colsum + n_ld), LDS_PTR(stage + 1280), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p.ln_stats + 2 * (long)(cm0 + wr * 128) + 4 * lane), LDS_PTR(stage), 16, 0, 0);
+        }
+    };
 
     int buf = 0;                                // LDS buffer of the K-step being computed (stream parity)
-    auto k_step = [&](auto first_tag) {
+    auto k_step = [&](auto first_tag, bool last) {
         constexpr bool FIRST = decltype(first_tag)::value;
         // first half: (A_h0, B_h0), (A_h0, B_h1)
-        load_a(buf, SLOT_A0);
+        load_a(buf, SLOT_A0, 0, 4);
         load_b(buf, SLOT_B0, 0);
         load_b(buf, SLOT_B1, 1);
-        if (ok1) issue(buf ^ 1, SLOT_A1, a1, w2);
+        issue(buf ^ 1, SLOT_A1, a1, w2);
+        if (last) stage_fetch();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         OTTER_SEG_END()
         OTTER_MFMA_SEG2(0, 0, 1)
         OTTER_SEG_END()
         // second half: (A_h1, B_h1), (A_h1, B_h0)
-        load_a(buf, SLOT_A1);
-        if (ok2) {
-            issue(buf, SLOT_A0, a2, w2);
-            issue(buf, SLOT_B0, a2, w2);
-            issue(buf, SLOT_B1, a2, w2);
-        }
+        load_a(buf, SLOT_A1, 0, 4);
+        issue(buf, SLOT_A0, a2, w2);
+        issue(buf, SLOT_B0, a2, w2);
+        issue(buf, SLOT_B1, a2, w2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (late) { OTTER_RETIRE_NEXT() }
         OTTER_SEG_END()
@@ -252,15 +274,14 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
         if (!late) { OTTER_RETIRE_NEXT() }
         OTTER_SEG_END()
         a1 = a2;
-        ok1 = ok2;
         advance2();
         buf ^= 1;
     };
 
     if (late) { OTTER_SEG_END() }
     while (true) {
-    k_step(std::true_type{});
-    for (int t = 1; t < nkt; ++t) k_step(std::false_type{});
+    k_step(std::true_type{}, nkt == 1);
+    for (int t = 1; t < nkt; ++t) k_step(std::false_type{}, t == nkt - 1);
 
     // ---- store the tile (the next tile's first K-steps are landing meanwhile) ----
     // lane (g, li): rows 16mt + 4g + r, columns 4li + 0..3 of the wave's 64.
@@ -272,52 +293,45 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     {
         const int n_u = cn0 + wc * 64;
         const int n = n_u + 4 * li;
-        if (n < p.N) {
-            constexpr int EO = OUT_F32 ? 4 : 2;                    // bytes per output element
-            typedef typename Half16<T>::v4 h4;
-            typedef typename Half16<T>::v2 h2;
-            const unsigned lane_c = (unsigned)(4 * g) * (unsigned)(p.ldc * EO) + (unsigned)(4 * li * EO);
-            const unsigned lane_r = (unsigned)(4 * g) * (unsigned)(p.ldr * EO) + (unsigned)(4 * li * EO);
-            const unsigned lane_s = (unsigned)(4 * g) * 8u;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = bv;
-            if (p.bias) bv = *(const f32x4*)(p.bias + n);
-            if (LNF) cs = *(const f32x4*)(p.ln_colsum + n);
+        const bool n_ok = n < p.N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = bv;
+        if (p.bias) bv = *(const f32x4*)(stage + 1024 + 16 * li);
+        if (LNF) cs = *(const f32x4*)(stage + 1280 + 16 * li);
+        {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int row_u = cm0 + wr * 128 + s * 64;                              // wave-uniform
                 char* c_u = (char*)p.C + ((long)row_u * p.ldc + n_u) * EO;
-                const char* r_u = RES ? (const char*)p.residual + ((long)row_u * p.ldr + n_u) * EO : nullptr;
-                const char* s_u = LNF ? (const char*)(p.ln_stats + 2 * (long)row_u) : nullptr;
-                // The residual is usually the output buffer itself, so the compiler must keep every load ahead of the next
-                // store and, loads and stores retiring in order, would wait out one memory round trip per row: fetch the
-                // residual of 16 rows first, then store the 16 rows.
+                unsigned lo_c = lane_c, lo_r = lane_r;
+                asm volatile("" : "+v"(lo_c), "+v"(lo_r));
+                // fp32 residual (64 registers per half: no room to fetch it ahead): the 16 rows of the half first, then
+                // their stores
                 f32x4 rf[RES && OUT_F32 ? 16 : 1];
                 h4 rh[RES && !OUT_F32 ? 16 : 1];
-                f32x2 st[LNF ? 16 : 1];         // (mean, rstd) of the 16 rows, fetched ahead of the stores for the same reason
-                if (LNF) {
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) st[mt * 4 + r] = *(const f32x2*)(s_u + (mt * 16 + r) * 8 + lane_s);
-                }
-                if (RES) {
+                if (RES && n_ok) {
+                    const char* r_u = (const char*)p.residual + ((long)row_u * p.ldr + n_u) * EO;
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const char* src = r_u + (long)(mt * 16 + r) * (p.ldr * EO) + lane_r;
+                            const char* src = r_u + (long)(mt * 16 + r) * (p.ldr * EO) + (unsigned long)lo_r;
                             if constexpr (OUT_F32) rf[mt * 4 + r] = *(const f32x4*)src;
                             else rh[mt * 4 + r] = *(const h4*)src;
                         }
                 }
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt) {
+                    f32x4 st2[LNF ? 2 : 1];                 // (mean, rstd) of rows r = 0, 1 and of rows r = 2, 3
+                    if (LNF) {
+                        st2[0] = *(const f32x4*)(stage + (s * 64 + mt * 16 + 4 * g) * 8);
+                        st2[1] = *(const f32x4*)(stage + (s * 64 + mt * 16 + 4 * g) * 8 + 16);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v[4] = {acc[s][0][mt][0][r], acc[s][0][mt][1][r], acc[s][1][mt][0][r], acc[s][1][mt][1][r]};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if (LNF) v[e] = __builtin_fmaf(__builtin_fmaf(-st[mt * 4 + r][0], cs[e], v[e]), st[mt * 4 + r][1], bv[e]);
+                            if (LNF) v[e] = __builtin_fmaf(__builtin_fmaf(-st2[r >> 1][2 * (r & 1)], cs[e], v[e]), st2[r >> 1][2 * (r & 1) + 1], bv[e]);
                             else v[e] += bv[e];
                             v[e] = act256<ACT>(v[e]);
                             if (RES) {
@@ -325,16 +339,17 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                                 else v[e] += (float)rh[mt * 4 + r][e];
                             }
                         }
-                        char* dst = c_u + (long)(mt * 16 + r) * (p.ldc * EO) + lane_c;
+                        char* dst = c_u + (long)(mt * 16 + r) * (p.ldc * EO) + (unsigned long)lo_c;
                         if constexpr (OUT_F32) {
-                            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+                            if (n_ok) *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
                         } else {
                             union { h2 h[2]; h4 q; } o;
                             o.h[0] = Half16<T>::pack_sat_hw(v[0], v[1]);
                             o.h[1] = Half16<T>::pack_sat_hw(v[2], v[3]);
-                            *(h4*)dst = o.q;
+                            if (n_ok) *(h4*)dst = o.q;
                         }
                     }
+                }
             }
         }
     }
@@ -343,6 +358,7 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     tile_origin(tile, cm0, cn0);
     }   // tile loop
     if (!late) { OTTER_SEG_END() }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA request may outlive the workgroup's LDS allocation
 #undef OTTER_SEG_END
 #undef OTTER_MFMA_SEG2
 #undef OTTER_RETIRE_NEXT

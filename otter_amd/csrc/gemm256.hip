@@ -139,33 +139,39 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     f32x4 acc[2][2][4][2];                      // [A half s][B half x][m-tile][n-tile]
     const bool late = wave >= 4;
 
-    // ---- the load stream (wave-uniform state).  Cursor 2 = the K-step two ahead of the one being computed (its A_h0,
-    // B_h0, B_h1 are requested next), cursor 1 = the K-step one ahead (its A_h1 is requested next). ----
+    // ---- the load stream (wave-uniform state, scalar registers).  Cursor 2 = the K-step two ahead of the one being
+    // computed (its A_h0, B_h0, B_h1 are requested next), cursor 1 = the K-step one ahead (its A_h1 is requested next).
+    // Advancing a cursor is a handful of scalar selects without a branch: it runs between a K-step's last barrier and the
+    // next load segment, which the other wave group's MFMA segment waits for.  The one expensive part, a tile's origin (a
+    // division), is computed once per tile after the epilogue's stores, a tile ahead of the stream: `nx_*` is the tile the
+    // stream enters at its next wrap.  (The stream wraps in K-step nkt - 3 of the tile being computed: nkt >= 4.)
     int tile = blockIdx.x;                      // the tile being computed
     int cm0, cn0;                               // its origin
     tile_origin(tile, cm0, cn0);
-    int s_tile = tile, s_k = 0;
     unsigned a2 = (unsigned)cm0 * (unsigned)(p.lda * 2);         // byte offsets of the K-step's first A row / weight row
     unsigned w2 = (unsigned)cn0 * (unsigned)(p.K * 2);
-    bool ok2 = true;
-    // (past the end of the stream the cursor stays on the last K-step it reached: requests keep being made -- see k_step --
-    //  and have to name memory that exists)
+    int s_k = 0;                                // K-step of cursor 2 inside its tile
+    unsigned s_inc = 1, s_step = 128;           // both 0 once the stream has ended: the cursor stays on the last K-step it
+                                                // reached (requests keep being made -- see k_step -- and must name memory that exists)
+    int nx_tile, nx_m0 = 0, nx_n0 = 0;          // the stream's next tile; its origin (valid while nx_tile < nwg)
+    int cnx_m0 = 0, cnx_n0 = 0;                 // origin of the tile computed next (= the tile the stream entered last)
+    auto prepare_next = [&](int t) {
+        nx_tile = t;
+        if (t < nwg) tile_origin(t, nx_m0, nx_n0);
+    };
+    prepare_next(tile + gridDim.x);
     auto advance2 = [&]() {
-        if (!ok2) return;
-        if (++s_k < nkt) {
-            a2 += 128;
-            w2 += 128;
-        } else {
-            s_k = 0;
-            s_tile += gridDim.x;
-            ok2 = s_tile < nwg;
-            if (ok2) {
-                int m0, n0;
-                tile_origin(s_tile, m0, n0);
-                a2 = (unsigned)m0 * (unsigned)(p.lda * 2);
-                w2 = (unsigned)n0 * (unsigned)(p.K * 2);
-            }
-        }
+        s_k += s_inc;
+        const bool wrap = s_k == nkt;
+        const bool more = nx_tile < nwg;
+        const bool enter = wrap && more, end = wrap && !more;
+        a2 = enter ? (unsigned)nx_m0 * (unsigned)(p.lda * 2) : a2 + (wrap ? 0u : s_step);
+        w2 = enter ? (unsigned)nx_n0 * (unsigned)(p.K * 2) : w2 + (wrap ? 0u : s_step);
+        cnx_m0 = enter ? nx_m0 : cnx_m0;
+        cnx_n0 = enter ? nx_n0 : cnx_n0;
+        s_k = enter ? 0 : (end ? nkt - 1 : s_k);
+        s_inc = end ? 0u : s_inc;
+        s_step = end ? 0u : s_step;
     };
     // K-step 0 completely, plus the three half-tiles of K-step 1 that the second half of K-step -1 would request
     issue(0, SLOT_A0, a2, w2);
@@ -350,12 +356,20 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                         }
                     }
                 }
+                // The early group stores its first 64 rows beside the late group's last MFMA segment of the tile and its
+                // second 64 beside the late group's whole epilogue: two waves per SIMD share the vector ALU at twice the
+                // rate one wave can issue at, so the two groups' epilogues overlap instead of following each other.  One
+                // extra barrier per tile and group keeps the groups one segment apart.
+                if (s == 0 && !late) { OTTER_SEG_END() }
             }
+            if (late) { OTTER_SEG_END() }
         }
     }
     tile += gridDim.x;
     if (tile >= nwg) break;
-    tile_origin(tile, cm0, cn0);
+    cm0 = cnx_m0;                               // the stream entered this tile during the K-loop above
+    cn0 = cnx_n0;
+    prepare_next(tile + gridDim.x);
     }   // tile loop
     if (!late) { OTTER_SEG_END() }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA request may outlive the workgroup's LDS allocation
@@ -402,7 +416,7 @@ int dispatch256(const Gemm256Args& a, int act, bool out_f32, bool res, hipStream
 // Shapes the 256x256 kernel accepts (checked by the caller in gemm.hip, which owns the argument validation).
 bool otter_gemm256_eligible(int dtype, long lda, int n_pad, int M, int N, int K, const void* C, long ldc) {
     if (dtype != DT_BF16 && dtype != DT_F16) return false;
-    if (M < 1024 || N < 256 || K % 64 != 0) return false;                       // small problems: 128x128 tiles fill the chip better
+    if (M < 1024 || N < 256 || K % 64 != 0 || K < 256) return false;                       // small problems: 128x128 tiles fill the chip better
     if (N % 8 != 0 || ldc % 8 != 0 || ((uintptr_t)C & 15) != 0) return false;     // a lane stores 4 consecutive columns as one vector; rows stay 16-byte aligned
     if (n_pad < ((N + TN - 1) / TN) * TN) return false;                          // weight rows must cover whole 256-column tiles
     if ((long)(M / TM) * ((N + TN - 1) / TN) < 128) return false;                // fewer tiles than half the CUs: smaller tiles fill the chip better

@@ -227,10 +227,8 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     wg_barrier();                                           \
     __builtin_amdgcn_sched_barrier(0);
 #define OTTER_MFMA_SEG2(S, X0, X1)                          \
-    __builtin_amdgcn_s_setprio(1);                          \
     OTTER_QUADRANT(S, X0)                                   \
-    OTTER_QUADRANT(S, X1)                                   \
-    __builtin_amdgcn_s_setprio(0);
+    OTTER_QUADRANT(S, X1)
 #define OTTER_RETIRE_NEXT() asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 
     // ---- epilogue operands that come from memory.  Loaded into registers where they are used, each costs the epilogue a
@@ -278,16 +276,40 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
         OTTER_SEG_END()
         OTTER_MFMA_SEG2(1, 1, 0)
         if (!late) { OTTER_RETIRE_NEXT() }
-        OTTER_SEG_END()
+        if (!last) { OTTER_SEG_END() }          // (a tile's last K-step: the barrier follows the epilogue's requests, below)
         a1 = a2;
         advance2();
         buf ^= 1;
     };
 
-    if (late) { OTTER_SEG_END() }
+    if (late) {
+        // static priority for the group that was dispatched second (it loses the age-based arbitration of the SIMD's issue
+        // slots in every segment otherwise); no per-segment flips
+        __builtin_amdgcn_s_setprio(1);
+        OTTER_SEG_END()
+    }
     while (true) {
     k_step(std::true_type{}, nkt == 1);
     for (int t = 1; t < nkt; ++t) k_step(std::false_type{}, t == nkt - 1);
+    // 16-bit residual: all 32 rows of the lane are requested here, behind the last MFMA segment and ahead of its barrier
+    // (the fragment registers are free now): they travel while this group waits at the barrier -- the late group through the
+    // early group's first stores -- and no load has to queue behind a store.
+    h4 rh[2][RES && !OUT_F32 ? 16 : 1];
+    if constexpr (RES && !OUT_F32) {
+        // lanes whose columns lie beyond N (last column tile of an N that is not a multiple of 256) read the tile's first
+        // columns instead: in bounds, never used
+        unsigned lo = lane_r - (unsigned)(4 * li * EO) + (cn0 + wc * 64 + 4 * li < p.N ? (unsigned)((wc * 64 + 4 * li) * EO) : 0u);
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const char* r_u = (const char*)p.residual + ((long)(cm0 + wr * 128 + s * 64) * p.ldr + cn0) * EO;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rh[s][mt * 4 + r] = *(const h4*)(r_u + (long)(mt * 16 + r) * (p.ldr * EO) + (unsigned long)lo);
+        }
+    }
+    OTTER_SEG_END()
 
     // ---- store the tile (the next tile's first K-steps are landing meanwhile) ----
     // lane (g, li): rows 16mt + 4g + r, columns 4li + 0..3 of the wave's 64.
@@ -303,6 +325,14 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = bv;
         if (p.bias) bv = *(const f32x4*)(stage + 1024 + 16 * li);
         if (LNF) cs = *(const f32x4*)(stage + 1280 + 16 * li);
+        if constexpr (RES && !OUT_F32) {
+            // one wait for all 32 residual rows here, where nothing younger is in flight: the compiler's wait in front of the
+            // second half would otherwise also cover the first half's stores
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(rh[s][i]));
+        }
         {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -310,19 +340,16 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                 char* c_u = (char*)p.C + ((long)row_u * p.ldc + n_u) * EO;
                 unsigned lo_c = lane_c, lo_r = lane_r;
                 asm volatile("" : "+v"(lo_c), "+v"(lo_r));
-                // fp32 residual (64 registers per half: no room to fetch it ahead): the 16 rows of the half first, then
-                // their stores
+                // fp32 residual (64 registers per half): the 16 rows of the half first, then their stores
                 f32x4 rf[RES && OUT_F32 ? 16 : 1];
-                h4 rh[RES && !OUT_F32 ? 16 : 1];
-                if (RES && n_ok) {
+                if (RES && OUT_F32 && n_ok) {
                     const char* r_u = (const char*)p.residual + ((long)row_u * p.ldr + n_u) * EO;
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const char* src = r_u + (long)(mt * 16 + r) * (p.ldr * EO) + (unsigned long)lo_r;
-                            if constexpr (OUT_F32) rf[mt * 4 + r] = *(const f32x4*)src;
-                            else rh[mt * 4 + r] = *(const h4*)src;
+                            rf[mt * 4 + r] = *(const f32x4*)src;
                         }
                 }
 #pragma unroll
@@ -342,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                             v[e] = act256<ACT>(v[e]);
                             if (RES) {
                                 if constexpr (OUT_F32) v[e] += rf[mt * 4 + r][e];
-                                else v[e] += (float)rh[mt * 4 + r][e];
+                                else v[e] += (float)rh[s][mt * 4 + r][e];
                             }
                         }
                         char* dst = c_u + (long)(mt * 16 + r) * (p.ldc * EO) + (unsigned long)lo_c;

@@ -11,6 +11,8 @@
 //     addressed with the same key permutation.
 //   * LDS images are XOR-swizzled by 16-byte chunk: K for ds_read_b128 fragment reads, V for the transposed reads.
 // Policy kernel (attn_policy): head_dim 96, at most 32 keys; one wave per (episode, head, query), fp32.
+#include <type_traits>
+
 #include "common.hpp"
 #include "otter_hip.h"
 
@@ -36,10 +38,13 @@ __device__ __forceinline__ int v_swz(int row, int chunk) { return chunk ^ (((row
 // latency is hidden by hand: the K fragments of the next batch of key tiles are requested before the MFMAs of the
 // current batch are issued.  Every key tile is computed, also rows past L: a wave-uniform skip would put a branch
 // between an MFMA and the first read of its accumulator.
-template <typename T, int NT>
-__device__ __forceinline__ void tile_scores(const char* sK, int k_row, int k_sw, int g, const typename Half16<T>::v8 (&qf)[2], f32x4 (&s)[NT]) {
+// NQ query tiles (1 or 2) share every K fragment read: the LDS serves 8 waves per CU, and a query tile that reads all of K
+// and all of V for itself (68 KiB per tile and wave) costs as much LDS time per round of tiles as its MFMAs or its
+// softmax take; with two tiles per pass that is halved.
+template <typename T, int NT, int NQ>
+__device__ __forceinline__ void tile_scores(const char* sK, int k_row, int k_sw, int g, const typename Half16<T>::v8 (&qf)[2][2], f32x4 (&s)[NQ][NT]) {
     typedef typename Half16<T>::v8 v8;
-    constexpr int KB = 4, NB = (NT + KB - 1) / KB;
+    constexpr int KB = NQ == 2 ? 2 : 4, NB = (NT + KB - 1) / KB;
     v8 kf[2][KB][2];
     auto read_k = [&](int b, v8 (&dst)[KB][2]) {
 #pragma unroll
@@ -59,13 +64,15 @@ __device__ __forceinline__ void tile_scores(const char* sK, int k_row, int k_sw,
         for (int i = 0; i < KB; ++i)
             if (b * KB + i < NT) {
                 const int kt = b * KB + i;
-                s[kt] = Half16<T>::mfma32(kf[b & 1][i][0], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) s[t][kt] = Half16<T>::mfma32(kf[b & 1][i][0], qf[t][0], (f32x4){0.f, 0.f, 0.f, 0.f});
             }
 #pragma unroll
         for (int i = 0; i < KB; ++i)
             if (b * KB + i < NT) {
                 const int kt = b * KB + i;
-                s[kt] = Half16<T>::mfma32(kf[b & 1][i][1], qf[1], s[kt]);
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) s[t][kt] = Half16<T>::mfma32(kf[b & 1][i][1], qf[t][1], s[t][kt]);
             }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -94,16 +101,20 @@ __device__ __forceinline__ void tile_softmax(f32x4 (&s)[NT], int lim, float c2) 
         for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c2, off));   // 2^(-inf) = 0 for masked keys
 }
 
-// O^T = V^T . P^T and the row sums; returns 1 / sum of this lane's query.  V^T fragments (two transposed reads per MFMA)
-// are requested a key-tile pair ahead of their MFMAs.
-template <typename T, int NT>
-__device__ __forceinline__ float tile_pv(const char* sV, const f32x4 (&s)[NT], int g, int li, f32x4 (&o)[4]) {
+// O^T = V^T . P^T and the row sums for NQ query tiles that share the V^T fragment reads; inv[t] = 1 / sum of this lane's
+// query of tile t.  V^T fragments (two transposed reads per MFMA) are requested a key-tile pair ahead of their MFMAs.
+template <typename T, int NT, int NQ>
+__device__ __forceinline__ void tile_pv(const char* sV, const f32x4 (&s)[NQ][NT], int g, int li, f32x4 (&o)[NQ][4], float (&inv)[NQ]) {
     typedef typename Half16<T>::v8 v8;
     constexpr int NP = (NT + 1) / 2;               // key-tile pairs of the second product (K = 32 per MFMA)
     const int vr = li >> 2;                        // lane li of group g addresses row r0 + (li>>2), bytes (li&3)*8 of the d-tile
-    f32x4 osum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 osum[NQ];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NQ; ++t) {
+        osum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     v8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
@@ -130,19 +141,25 @@ __device__ __forceinline__ float tile_pv(const char* sV, const f32x4 (&s)[NT], i
         constexpr T zero = (T)0.0f;
         const bool has_hi = 2 * s2 + 1 < NT;
         if (s2 + 1 < NP) read_v(s2 + 1, vf[(s2 + 1) & 1]);
-        v8 pf;
+        v8 pf[NQ];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pf[r] = Half16<T>::from_unit(s[2 * s2][r]);
-            pf[4 + r] = has_hi ? Half16<T>::from_unit(s[has_hi ? 2 * s2 + 1 : 0][r]) : zero;
-        }
+        for (int t = 0; t < NQ; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[t][r] = Half16<T>::from_unit(s[t][2 * s2][r]);
+                pf[t][4 + r] = has_hi ? Half16<T>::from_unit(s[t][has_hi ? 2 * s2 + 1 : 0][r]) : zero;
+            }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = Half16<T>::mfma32(vf[s2 & 1][dt], pf, o[dt]);
-        osum = Half16<T>::mfma32(ones, pf, osum);          // every accumulator row = sum over this pair's 32 keys, per query (lane)
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) o[t][dt] = Half16<T>::mfma32(vf[s2 & 1][dt], pf[t], o[t][dt]);
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) osum[t] = Half16<T>::mfma32(ones, pf[t], osum[t]);   // every accumulator row = sum over this pair's 32 keys, per query (lane)
         __builtin_amdgcn_sched_barrier(0);
     }
-    return __builtin_amdgcn_rcpf(osum[0]);
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) inv[t] = __builtin_amdgcn_rcpf(osum[t][0]);
 }
 
 // (a convex combination of 16-bit values: no saturation needed on the way back to 16 bits)
@@ -158,14 +175,16 @@ __device__ __forceinline__ void tile_store(T* row_out, const f32x4 (&o)[4], floa
     }
 }
 
-// One workgroup per (sequence, head): any length up to 592, optional causal mask.
+// One workgroup per (sequence, head): any length up to 592, optional causal mask.  A wave works on its query tiles two at a
+// time (NT <= 18: the score rows of two tiles fit the registers), a last odd one alone.
 template <typename T, int NT, int LS, int NW>      // NW waves per workgroup share the query tiles
-__global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, NT <= 18 ? 2 : 1) void attn_d64(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 v8;
     const T* qkv = (const T*)p.qkv;
     T* outp = (T*)p.out;
     constexpr int LK = NT * 16;
+    constexpr bool DUAL = NT <= 18;
     char* sK = smem;
     char* sV = smem + LK * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,18 +195,19 @@ __global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
     const int hd = p.heads * 64;
     const int g = lane >> 4, li = lane & 15;
 
-    // first query tile of this wave: issue its loads before the K/V staging so both latencies overlap
+    // first query tiles of this wave: issue their loads before the K/V staging so both latencies overlap
     auto load_q = [&](int qt, v8 (&qf)[2]) {
         const int qc = min(qt * 16 + li, L - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             qf[ks] = *(const v8*)(qkv + (row0 + qc) * p.ld + h * 64 + ks * 32 + g * 8);
     };
-    v8 qf[2];
+    v8 qf[2][2];
     // NT is rarely a multiple of NW, so some wave gets one tile more; which one rotates with the workgroup id so that the
     // workgroups sharing a CU do not all put their extra tile on the same SIMD
     const int wslot = (wave + (blockIdx.x ^ (blockIdx.x >> 3) ^ (blockIdx.x >> 8))) % NW;
-    load_q(wslot < NT ? wslot : 0, qf);
+    load_q(wslot < NT ? wslot : 0, qf[0]);
+    if (DUAL) load_q(wslot + NW < NT ? wslot + NW : 0, qf[1]);
 
     // ---- stage K and V of this head by LDS-DMA: one instruction = 8 rows x 128 bytes, lane-linear destination, the
     //      chunk swizzle applied on the source address.  Rows >= L repeat row L-1 (finite data; their keys are masked). ----
@@ -205,21 +225,38 @@ __global__ __launch_bounds__(NW * 64) void attn_d64(AttnArgs p) {
     const int k_sw = (li >> 1) & 7;
     const float c2 = p.scale * 1.44269504088896341f;
 
-    for (int qt = wslot; qt < NT; qt += NW) {
-        const int q = qt * 16 + li;                // this lane's query
+    // NQ tiles qt, qt + NW (the second only with NQ = 2); nxt = this wave's tile after them (its query rows are requested
+    // while the softmax runs)
+    auto process = [&](auto nq_tag, int qt, int nxt) {
+        constexpr int NQ = decltype(nq_tag)::value;
         // The K fragments do not depend on the query tile; left alone the compiler keeps all of them in registers
-        // across the loop (2*NT*4 = 136 VGPRs), which leaves too few to keep the V^T reads of the second product in
+        // across the loop, which leaves too few to keep the V^T reads of the second product in
         // flight.  An opaque copy of the row offset keeps the (cheap) LDS reads inside the loop.
         int k_row = k_row_off;
         asm volatile("" : "+v"(k_row));
-        f32x4 s[NT];
-        tile_scores<T, NT>(sK, k_row, k_sw, g, qf, s);
-        if (qt + NW < NT) load_q(qt + NW, qf);      // lands while the softmax runs
-        tile_softmax<NT, LS>(s, (causal ? min(L, q + 1) : L) - 4 * g, c2);
-        f32x4 o[4];
-        const float inv = tile_pv<T, NT>(sV, s, g, li, o);
-        if (q < L) tile_store<T>(outp + (row0 + q) * p.ldo + h * 64, o, inv, g);
+        f32x4 s[NQ][NT];
+        tile_scores<T, NT, NQ>(sK, k_row, k_sw, g, qf, s);
+        if (nxt < NT) load_q(nxt, qf[0]);           // lands while the softmax runs
+        if (DUAL && nxt + NW < NT) load_q(nxt + NW, qf[1]);
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            const int q = (qt + t * NW) * 16 + li;          // this lane's query
+            tile_softmax<NT, LS>(s[t], (causal ? min(L, q + 1) : L) - 4 * g, c2);
+        }
+        f32x4 o[NQ][4];
+        float inv[NQ];
+        tile_pv<T, NT, NQ>(sV, s, g, li, o, inv);
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            const int q = (qt + t * NW) * 16 + li;
+            if (q < L) tile_store<T>(outp + (row0 + q) * p.ldo + h * 64, o[t], inv[t], g);
+        }
+    };
+    int qt = wslot;
+    if constexpr (DUAL) {
+        for (; qt + NW < NT; qt += 2 * NW) process(std::integral_constant<int, 2>{}, qt, qt + 2 * NW);
     }
+    for (; qt < NT; qt += NW) process(std::integral_constant<int, 1>{}, qt, qt + NW);
 }
 
 template <typename T, int NT, int LS, int NW = 4>

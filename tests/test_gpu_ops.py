@@ -117,7 +117,7 @@ def test_gemm_residual_in_operand_type(dev, m, n, k, dtype):
         ops.gemm(a, wp, n, bias, residual=x.to(torch.float16 if dt == torch.bfloat16 else torch.bfloat16))
 
 
-@pytest.mark.parametrize("m,n,k", [(32768 // 4, 1024, 64), (300, 256, 128), (70, 64, 64)])
+@pytest.mark.parametrize("m,n,k", [(32768 // 4, 1024, 256), (300, 256, 128), (70, 64, 64)])
 def test_gemm_fp16_output_saturates(dev, m, n, k):
     """fp16 outputs beyond +-65504 clamp to the largest finite value (never an infinity) on all three kernels, with and
     without the 16-bit residual; values inside the range are untouched by the clamp."""
@@ -166,6 +166,41 @@ def test_gemm_with_folded_layernorm(dev, m, n, k, act, dtype):
         out = ops.gemm(x, wp, n, bf, act=ACTS[act], ln_stats=stats, ln_colsum=cs, **kw)
         tol = 3e-2 if dtype == "bf16" else 4e-3                          # rounding of W * gamma and of the output
         torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("m,n,k", [(16384, 1280, 256),      # 320 tiles on 256 CUs: workgroups with two tiles beside workgroups with one
+                                   (32768, 1000, 320),      # N not a multiple of 256 (lanes beyond N), odd number of K-steps
+                                   (33024, 768, 1024),      # 129 x 3 = 387 tiles: an uneven second round
+                                   (8192, 1024, 256)])      # 128 tiles: every workgroup's stream ends inside its first tile
+def test_gemm_256_tile_stream_shapes(dev, m, n, k):
+    """The 256x256 kernel's load stream runs across a workgroup's tiles: shapes where the tile counts per workgroup differ,
+    the stream ends at different points and the column tiles are partial -- plain, folded LayerNorm + QuickGELU, in-place
+    16-bit residual and fp32 output, each against a GPU fp32 product of the same 16-bit operands."""
+    from otter_amd import ops
+    dt = torch.float16
+    x = (_randn(51, m, k) * 2 + 0.3).to(dev).to(dt)
+    w = (_randn(52, n, k) / math.sqrt(k)).to(dev)
+    bias = _randn(53, n).to(dev)
+    wp = ops.pack_weight(w, dt)
+    prod = x.float() @ wp[:n, :k].float().t() + bias
+    out = ops.gemm(x, wp, n, bias)
+    torch.testing.assert_close(out.float(), prod, rtol=2e-3, atol=2e-3)
+    out32 = ops.gemm(x, wp, n, bias, act=ACTS["relu"], out_f32=True)
+    torch.testing.assert_close(out32, torch.relu(prod), rtol=1e-4, atol=1e-4)
+    res = (_randn(54, m, n) * 2).to(dev).to(dt)
+    xs = res.clone()
+    ops.gemm(x, wp, n, bias, residual=xs, out=xs)
+    torch.testing.assert_close(xs.float(), prod + res.float(), rtol=3e-3, atol=3e-3)
+    gamma = (_randn(55, k) * 0.3 + 1).to(dev)
+    beta = (_randn(56, k) * 0.2).to(dev)
+    wf, bfold, cs = ops.fold_layernorm(w, bias, gamma, beta, dt, dev)
+    ref = torch.nn.functional.layer_norm(x.float(), (k,), gamma, beta, 1e-5) @ w.t() + bias
+    ref = ref * torch.sigmoid(1.702 * ref)
+    out = ops.gemm(x, wf, n, bfold, act=ACTS["quickgelu"], ln_stats=ops.row_stats(x), ln_colsum=cs)
+    torch.testing.assert_close(out.float(), ref, rtol=4e-3, atol=4e-3)
+    # the same launches again on the same buffers: nothing left over from the previous launch's stream
+    out2 = ops.gemm(x, wf, n, bfold, act=ACTS["quickgelu"], ln_stats=ops.row_stats(x), ln_colsum=cs)
+    assert torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])

@@ -357,6 +357,49 @@ def test_published_clip_weights_load_into_the_model(tmp_path):
         load_clip_weights(model, path)
 
 
+def test_transformers_layout_safetensors_file_loads_and_matches_the_oracle_tower(tmp_path):
+    """A `transformers.CLIPModel` checkpoint (safetensors, Hugging Face key layout) fills clip_model.*: the converted tensors
+    are the ones the independent mapping of the oracle cross-check produces, and the oracle's vision tower on them gives what
+    the transformers model itself computes."""
+    transformers = pytest.importorskip("transformers")
+    from safetensors.torch import save_file
+    from otter_amd.clip_weights import load_clip_weights
+    from otter_amd.config import ModelConfig, SharedConfig, clip_arch
+    from otter_amd.otter import OTTER
+    from oracle import clip_ref
+    from tests.test_oracle_clip import _hf_to_openai
+    arch = clip_arch("tiny-test")
+    cfg = transformers.CLIPConfig(
+        text_config=dict(hidden_size=arch.transformer_width, intermediate_size=4 * arch.transformer_width, num_hidden_layers=arch.transformer_layers,
+                         num_attention_heads=arch.transformer_heads, vocab_size=arch.vocab_size, max_position_embeddings=arch.context_length,
+                         hidden_act="quick_gelu", projection_dim=arch.embed_dim),
+        vision_config=dict(hidden_size=arch.vision_width, intermediate_size=4 * arch.vision_width, num_hidden_layers=arch.vision_layers,
+                           num_attention_heads=arch.vision_heads, image_size=arch.image_resolution, patch_size=arch.vision_patch_size,
+                           hidden_act="quick_gelu", projection_dim=arch.embed_dim),
+        projection_dim=arch.embed_dim)
+    torch.manual_seed(5)
+    hf = transformers.CLIPModel(cfg).eval()
+    path = str(tmp_path / "model.safetensors")
+    save_file({k: v.contiguous() for k, v in hf.state_dict().items()}, path)
+    mc = ModelConfig(clip_model="tiny-test", transformer_dim=128, transformer_layers=2, transformer_heads=2, vision_pooling_output_dim=128,
+                     text_pooling_output_dim=64, proprio_hidden_dim=64, proprio_output_dim=32, pooling_heads=4)
+    model = OTTER(mc, SharedConfig(image_size=112, seq_length=4, action_horizon=4))
+    unused = load_clip_weights(model, path)
+    assert unused == []
+    sd = model.state_dict()
+    want = _hf_to_openai(hf.state_dict(), arch.vision_layers, arch.transformer_layers)
+    for k, v in want.items():
+        assert torch.equal(sd[k], v.float()), k
+    assert torch.equal(sd["clip_model.logit_scale"], hf.state_dict()["logit_scale"])
+    # and the tensors mean what they should: pooled image embedding of the oracle tower == transformers' own
+    px = torch.randn(2, 3, 112, 112, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        ref = hf.get_image_features(pixel_values=px)
+        ref = ref if isinstance(ref, torch.Tensor) else ref.pooler_output
+    got = clip_ref.encode_image(px, {k: v.float() for k, v in sd.items()})
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("h,w,size", [(180, 320, 224), (720, 1280, 224), (300, 200, 224), (224, 224, 224), (512, 512, 112)])
 def test_resize_arithmetic_is_pil_bicubic_bit_for_bit(h, w, size):
     """The fixed-point tables and two-pass arithmetic the GPU resize kernel uses, against PIL itself (down-scaling with

@@ -280,7 +280,8 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, int n_pa
     }
     hipStream_t s = (hipStream_t)stream;
     // (the 256x256 kernel has the folded-LayerNorm epilogue for 16-bit outputs with no / QuickGELU / GELU activation only)
-    const bool ln256 = !ln_stats || (!out_f32 && act != OTTER_EPI_ACT_RELU);
+    // (... and it fetches the row statistics 16 bytes at a time)
+    const bool ln256 = !ln_stats || (!out_f32 && act != OTTER_EPI_ACT_RELU && aligned16(ln_stats));
     if (!(epilogue & OTTER_EPI_TILE_128) && ln256 && otter_gemm256_eligible(dtype, lda, n_pad, M, N, K, C, ldc)) {
         // Rows are independent: whole 256-row tiles go to the 256x256 kernel, the remaining (< 256) rows to the
         // 64x64 kernel.

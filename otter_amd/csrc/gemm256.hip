@@ -45,7 +45,7 @@ constexpr int TM = 256, TN = 256;
 constexpr int HALF_BYTES = 128 * 128;             // one half-tile
 constexpr int STAGE_BYTES = 2048;                 // per wave: epilogue operands staged through LDS (see stage_fetch)
 constexpr int LDS_BYTES = 2 * 4 * HALF_BYTES + 8 * STAGE_BYTES;     // 128 KiB of tiles + 16 KiB
-constexpr int GROUP_M256 = 4;
+constexpr int GROUP_M256 = 8;     // tile order: groups of 8 row tiles swept along N (measured against 2, 4, 16, 32 on the ViT-L shapes)
 
 struct Gemm256Args {
     const char* A; long lda;

@@ -340,20 +340,20 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                 char* c_u = (char*)p.C + ((long)row_u * p.ldc + n_u) * EO;
                 unsigned lo_c = lane_c, lo_r = lane_r;
                 asm volatile("" : "+v"(lo_c), "+v"(lo_r));
-                // fp32 residual (64 registers per half): the 16 rows of the half first, then their stores
-                f32x4 rf[RES && OUT_F32 ? 16 : 1];
-                if (RES && OUT_F32 && n_ok) {
-                    const char* r_u = (const char*)p.residual + ((long)row_u * p.ldr + n_u) * EO;
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const char* src = r_u + (long)(mt * 16 + r) * (p.ldr * EO) + (unsigned long)lo_r;
-                            rf[mt * 4 + r] = *(const f32x4*)src;
-                        }
-                }
+                // fp32 residual: the 8 rows of two m-tiles first (32 registers; all 16 of the half do not fit), then their stores
+                f32x4 rf[RES && OUT_F32 ? 8 : 1];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
+                    if (RES && OUT_F32 && n_ok && (mt & 1) == 0) {
+                        const char* r_u = (const char*)p.residual + ((long)row_u * p.ldr + n_u) * EO;
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const char* src = r_u + (long)((mt + m2) * 16 + r) * (p.ldr * EO) + (unsigned long)lo_r;
+                                rf[m2 * 4 + r] = *(const f32x4*)src;
+                            }
+                    }
                     f32x4 st2[LNF ? 2 : 1];                 // (mean, rstd) of rows r = 0, 1 and of rows r = 2, 3
                     if (LNF) {
                         st2[0] = *(const f32x4*)(stage + (s * 64 + mt * 16 + 4 * g) * 8);
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
                             else v[e] += bv[e];
                             v[e] = act256<ACT>(v[e]);
                             if (RES) {
-                                if constexpr (OUT_F32) v[e] += rf[mt * 4 + r][e];
+                                if constexpr (OUT_F32) v[e] += rf[(mt & 1) * 4 + r][e];
                                 else v[e] += (float)rh[s][mt * 4 + r][e];
                             }
                         }

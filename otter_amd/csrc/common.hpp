@@ -137,6 +137,20 @@ __device__ __forceinline__ float quick_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896341f * x));
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// The same function for epilogues whose pace the vector ALU sets (the erf-GELU tower MLPs of OpenCLIP checkpoints): x * Phi(x)
+// with Phi(-|x|) = 0.5 erfc(|x| / sqrt 2) from Abramowitz & Stegun 7.1.26 (erfc(z) = poly(1 / (1 + p z)) e^(-z^2), absolute
+// error 1.5e-7): 15 branch-free instructions, two of them transcendental, against ~45 with branches for the library erff.
+// |gelu_erf_fast(x) - x Phi(x)| <= 2e-7 * max(1, |x|) (checked on a 1e-5 grid over [-10, 10] in fp32 arithmetic).
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float q = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    q = __builtin_fmaf(q, t, 0.5f * 1.421413741f);
+    q = __builtin_fmaf(q, t, 0.5f * -0.284496736f);
+    q = __builtin_fmaf(q, t, 0.5f * 0.254829592f);
+    q = q * t * __builtin_amdgcn_exp2f(z * z * -1.44269504088896341f);      // 0.5 erfc(z) = Phi(-|x|)
+    return x * (x < 0.f ? q : 1.0f - q);
+}
 
 // Bijective remap of a linear workgroup id so that each of the 8 XCDs (which receive workgroups
 // round-robin) works on one contiguous chunk of the tile space and its private L2 sees neighbouring tiles.

@@ -63,7 +63,7 @@ enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU = 2, ACT_RELU = 3 };
 
 template <int ACT> __device__ __forceinline__ float act256(float v) {
     if (ACT == ACT_QUICKGELU) return quick_gelu(v);
-    if (ACT == ACT_GELU) return gelu_erf(v);
+    if (ACT == ACT_GELU) return gelu_erf_fast(v);
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     return v;
 }

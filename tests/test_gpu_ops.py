@@ -117,6 +117,22 @@ def test_gemm_residual_in_operand_type(dev, m, n, k, dtype):
         ops.gemm(a, wp, n, bias, residual=x.to(torch.float16 if dt == torch.bfloat16 else torch.bfloat16))
 
 
+def test_gemm_256_erf_gelu_epilogue_accuracy(dev):
+    """The 256x256 kernel's erf-GELU epilogue is a branch-free erfc approximation (OpenCLIP tower MLPs): through an
+    identity weight and an fp32 output it must match nn.GELU() to 1e-6 * max(1, |x|) over the whole fp16-exact grid."""
+    from otter_amd import ops
+    m, n = 32768, 256
+    x = torch.linspace(-9.0, 9.0, m * n, device=dev).view(m, n).half()
+    wp = ops.pack_weight(torch.eye(n, device=dev), torch.float16)
+    out = ops.gemm(x, wp, n, None, act=ACTS["gelu"], out_f32=True)
+    ref = torch.nn.functional.gelu(x.double())
+    err = (out.double() - ref).abs() / x.double().abs().clamp_min(1.0)
+    assert err.max().item() <= 1e-6, err.max().item()
+    # deep in the left tail the result keeps its sign and magnitude (no cancellation against 1)
+    tail = x < -5
+    assert (out[tail] <= 0).all() and torch.allclose(out[tail].double(), ref[tail], rtol=0.05, atol=1e-12)
+
+
 @pytest.mark.parametrize("m,n,k", [(32768 // 4, 1024, 256), (300, 256, 128), (70, 64, 64)])
 def test_gemm_fp16_output_saturates(dev, m, n, k):
     """fp16 outputs beyond +-65504 clamp to the largest finite value (never an infinity) on all three kernels, with and

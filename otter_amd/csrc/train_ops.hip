@@ -24,75 +24,96 @@ struct SGemm {
     int M, N, K, accumulate;
 };
 
-constexpr int SG_T = 64, SG_K = 32, SG_LD = SG_T + 4;
-constexpr int SG_E = SG_T * SG_K / 256;            // elements of each operand tile per thread and K-step
+constexpr int SG_K = 64;
 
+// The problems of the trainable tail are small (192 tokens x 768 columns), and fp32 MFMA gives a CU only ~0.6 TFLOP/s, so a
+// launch must spread over as many CUs as it can: T = 32 (one 16x16 MFMA tile per wave) when 64x64 tiles would number fewer
+// than two per CU, T = 64 (2x2 per wave) otherwise.  A launch is then a short chain of K-steps each waiting for its
+// operands: two K-steps of 64 are kept in flight in registers (the loads of K-step s+2 are requested as soon as K-step s has
+// been copied to LDS), and every per-element index, offset and row / column bound is computed once, ahead of the loop.
+template <int T>
 __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
-    __shared__ float As[SG_K][SG_LD];     // [k][m]
-    __shared__ float Bs[SG_K][SG_LD];     // [k][n]
+    constexpr int LD = T + 4, E = T * SG_K / 256, R = T / 32;      // E elements of each operand tile per thread and K-step
+    __shared__ float As[SG_K][LD];        // [k][m]
+    __shared__ float Bs[SG_K][LD];        // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int wm = wave & 1, wn = wave >> 1;
-    const int m0 = blockIdx.y * SG_T, n0 = blockIdx.x * SG_T;
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
     const bool a_kfast = p.sak == 1, b_nfast = p.sbn == 1;
 
-    f32x4 acc[2][2];
+    f32x4 acc[R][R];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < R; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // element e of a tile: the thread order follows whichever index is contiguous in memory
-    auto a_idx = [&](int e, int& k, int& m) { if (a_kfast) { k = e % SG_K; m = e / SG_K; } else { m = e % SG_T; k = e / SG_T; } };
-    auto b_idx = [&](int e, int& k, int& n) { if (b_nfast) { n = e % SG_T; k = e / SG_T; } else { k = e % SG_K; n = e / SG_K; } };
-    float av[SG_E], bv[SG_E];
-    auto fetch = [&](int k0) {
+    // element i of this thread in a tile: the thread order follows whichever index is contiguous in memory
+    int ka[E], kb[E], lds_a[E], lds_b[E];
+    long off_a[E], off_b[E];
+    unsigned ok_a = 0, ok_b = 0;           // bit i: the element's row / column exists
 #pragma unroll
-        for (int i = 0; i < SG_E; ++i) {
-            int k, m, n, kb;
-            a_idx(tid + 256 * i, k, m);
-            b_idx(tid + 256 * i, kb, n);
-            av[i] = (m0 + m < p.M && k0 + k < p.K) ? p.A[(long)(m0 + m) * p.sam + (long)(k0 + k) * p.sak] : 0.f;
-            bv[i] = (n0 + n < p.N && k0 + kb < p.K) ? p.B[(long)(k0 + kb) * p.sbk + (long)(n0 + n) * p.sbn] : 0.f;
+    for (int i = 0; i < E; ++i) {
+        const int e = tid + 256 * i;
+        int k, m, k2, n;
+        if (a_kfast) { k = e % SG_K; m = e / SG_K; } else { m = e % T; k = e / T; }
+        if (b_nfast) { n = e % T; k2 = e / T; } else { k2 = e % SG_K; n = e / SG_K; }
+        ka[i] = k; kb[i] = k2;
+        lds_a[i] = k * LD + m; lds_b[i] = k2 * LD + n;
+        off_a[i] = (long)(m0 + m) * p.sam + (long)k * p.sak;
+        off_b[i] = (long)k2 * p.sbk + (long)(n0 + n) * p.sbn;
+        ok_a |= (unsigned)(m0 + m < p.M) << i;
+        ok_b |= (unsigned)(n0 + n < p.N) << i;
+    }
+    float av[2][E], bv[2][E];              // two K-steps in flight
+    auto fetch = [&](float (&a)[E], float (&b)[E], int k0) {
+        const float* Ak = p.A + (long)k0 * p.sak;
+        const float* Bk = p.B + (long)k0 * p.sbk;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            a[i] = ((ok_a >> i) & 1u) && k0 + ka[i] < p.K ? Ak[off_a[i]] : 0.f;
+            b[i] = ((ok_b >> i) & 1u) && k0 + kb[i] < p.K ? Bk[off_b[i]] : 0.f;
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < p.K; k0 += SG_K) {
+    auto k_step = [&](float (&a)[E], float (&b)[E], int k_next) {
         __syncthreads();                  // previous K-step's fragments have been read
 #pragma unroll
-        for (int i = 0; i < SG_E; ++i) {
-            int k, m, n, kb;
-            a_idx(tid + 256 * i, k, m);
-            b_idx(tid + 256 * i, kb, n);
-            As[k][m] = av[i];
-            Bs[kb][n] = bv[i];
+        for (int i = 0; i < E; ++i) {
+            (&As[0][0])[lds_a[i]] = a[i];
+            (&Bs[0][0])[lds_b[i]] = b[i];
         }
         __syncthreads();
-        if (k0 + SG_K < p.K) fetch(k0 + SG_K);            // the next tile's loads are in flight under this step's MFMAs
+        if (k_next < p.K) fetch(a, b, k_next);            // two K-steps ahead, into the registers just copied out
 #pragma unroll
         for (int kk = 0; kk < SG_K / 4; ++kk) {
-            float a[2], b[2];
+            float fa[R], fb[R];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[kk * 4 + g][wm * 32 + i * 16 + li];
+            for (int i = 0; i < R; ++i) fa[i] = As[kk * 4 + g][wm * (T / 2) + i * 16 + li];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[kk * 4 + g][wn * 32 + j * 16 + li];
+            for (int j = 0; j < R; ++j) fb[j] = Bs[kk * 4 + g][wn * (T / 2) + j * 16 + li];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < R; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < R; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+    };
+    fetch(av[0], bv[0], 0);
+    if (SG_K < p.K) fetch(av[1], bv[1], SG_K);
+    for (int k0 = 0; k0 < p.K; k0 += 2 * SG_K) {
+        k_step(av[0], bv[0], k0 + 2 * SG_K);
+        if (k0 + SG_K < p.K) k_step(av[1], bv[1], k0 + 3 * SG_K);
     }
     // D layout: column (n) = lane & 15, row (m) = 4 * (lane >> 4) + r
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 32 + j * 16 + li;
+        for (int j = 0; j < R; ++j) {
+            const int n = n0 + wn * (T / 2) + j * 16 + li;
             if (n >= p.N) continue;
             const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + i * 16 + 4 * g + r;
+                const int m = m0 + wm * (T / 2) + i * 16 + 4 * g + r;
                 if (m >= p.M) continue;
                 float* c = p.C + (long)m * p.ldc + n;
                 const float v = acc[i][j][r] + bias;
@@ -497,9 +518,12 @@ extern "C" int otter_sgemm_strided(const float* A, long sa_m, long sa_k, const f
     if (M == 0 || N == 0) return OTTER_OK;
     OTTER_REQUIRE(M > 0 && N > 0 && K >= 0 && ldc >= N, OTTER_ERR_INVALID_ARGUMENT, "otter_sgemm_strided: bad sizes M=%d N=%d K=%d ldc=%ld", M, N, K, ldc);
     SGemm a{A, sa_m, sa_k, B, sb_k, sb_n, bias, C, ldc, M, N, K, accumulate ? 1 : 0};
-    dim3 grid((N + SG_T - 1) / SG_T, (M + SG_T - 1) / SG_T);
+    const bool small = (long)((N + 63) / 64) * ((M + 63) / 64) < 512;      // fewer than two 64x64 tiles per CU: 32x32 tiles (the fp32 MFMA rate of the busy CUs is the bound)
+    const int t = small ? 32 : 64;
+    dim3 grid((N + t - 1) / t, (M + t - 1) / t);
     OTTER_REQUIRE(grid.y < 65536, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_sgemm_strided: M=%d too large", M);
-    hipLaunchKernelGGL(sgemm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (small) hipLaunchKernelGGL(sgemm_strided_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(sgemm_strided_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
     OTTER_CHECK_LAUNCH("otter_sgemm_strided");
     return OTTER_OK;
 }

@@ -51,7 +51,6 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
     // element i of this thread in a tile: the thread order follows whichever index is contiguous in memory
     int ka[E], kb[E], lds_a[E], lds_b[E];
     long off_a[E], off_b[E];
-    unsigned ok_a = 0, ok_b = 0;           // bit i: the element's row / column exists
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         const int e = tid + 256 * i;
@@ -60,30 +59,48 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
         if (b_nfast) { n = e % T; k2 = e / T; } else { k2 = e % SG_K; n = e / SG_K; }
         ka[i] = k; kb[i] = k2;
         lds_a[i] = k * LD + m; lds_b[i] = k2 * LD + n;
-        off_a[i] = (long)(m0 + m) * p.sam + (long)k * p.sak;
-        off_b[i] = (long)k2 * p.sbk + (long)(n0 + n) * p.sbn;
-        ok_a |= (unsigned)(m0 + m < p.M) << i;
-        ok_b |= (unsigned)(n0 + n < p.N) << i;
+        off_a[i] = (long)min(m0 + m, p.M - 1) * p.sam + (long)k * p.sak;      // rows / columns past the edge: any address in bounds
+        off_b[i] = (long)k2 * p.sbk + (long)min(n0 + n, p.N - 1) * p.sbn;
     }
     float av[2][E], bv[2][E];              // two K-steps in flight
+    // Every load is unconditional (a load inside a branch would make the compiler drain the whole queue at its first use, and
+    // with it the K-step requested behind): out-of-range elements read a clamped address.
     auto fetch = [&](float (&a)[E], float (&b)[E], int k0) {
         const float* Ak = p.A + (long)k0 * p.sak;
         const float* Bk = p.B + (long)k0 * p.sbk;
+        if (k0 + SG_K <= p.K) {
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            a[i] = ((ok_a >> i) & 1u) && k0 + ka[i] < p.K ? Ak[off_a[i]] : 0.f;
-            b[i] = ((ok_b >> i) & 1u) && k0 + kb[i] < p.K ? Bk[off_b[i]] : 0.f;
+            for (int i = 0; i < E; ++i) {
+                a[i] = Ak[off_a[i]];
+                b[i] = Bk[off_b[i]];
+            }
+        } else {                          // the ragged last K-step: same number of requests, k clamped to K - 1
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                a[i] = Ak[off_a[i] + (long)(min(k0 + ka[i], p.K - 1) - (k0 + ka[i])) * p.sak];
+                b[i] = Bk[off_b[i] + (long)(min(k0 + kb[i], p.K - 1) - (k0 + kb[i])) * p.sbk];
+            }
         }
     };
-    auto k_step = [&](float (&a)[E], float (&b)[E], int k_next) {
+    auto k_step = [&](float (&a)[E], float (&b)[E], int k0, int k_next) {
         __syncthreads();                  // previous K-step's fragments have been read
+        // (rows / columns past the edge only feed outputs that are never stored; elements past K must be zero)
+        if (k0 + SG_K <= p.K) {
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            (&As[0][0])[lds_a[i]] = a[i];
-            (&Bs[0][0])[lds_b[i]] = b[i];
+            for (int i = 0; i < E; ++i) {
+                (&As[0][0])[lds_a[i]] = a[i];
+                (&Bs[0][0])[lds_b[i]] = b[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                (&As[0][0])[lds_a[i]] = k0 + ka[i] < p.K ? a[i] : 0.f;
+                (&Bs[0][0])[lds_b[i]] = k0 + kb[i] < p.K ? b[i] : 0.f;
+            }
         }
         __syncthreads();
-        if (k_next < p.K) fetch(a, b, k_next);            // two K-steps ahead, into the registers just copied out
+        fetch(a, b, k_next);              // two K-steps ahead, into the registers just copied out (past the end of K: clamped
+                                          // dummy requests -- a request count that varied by path would again cost a drain)
 #pragma unroll
         for (int kk = 0; kk < SG_K / 4; ++kk) {
             float fa[R], fb[R];
@@ -97,11 +114,13 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
                 for (int j = 0; j < R; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     };
-    fetch(av[0], bv[0], 0);
-    if (SG_K < p.K) fetch(av[1], bv[1], SG_K);
+    if (p.K > 0) {
+        fetch(av[0], bv[0], 0);
+        fetch(av[1], bv[1], SG_K);
+    }
     for (int k0 = 0; k0 < p.K; k0 += 2 * SG_K) {
-        k_step(av[0], bv[0], k0 + 2 * SG_K);
-        if (k0 + SG_K < p.K) k_step(av[1], bv[1], k0 + 3 * SG_K);
+        k_step(av[0], bv[0], k0, k0 + 2 * SG_K);
+        if (k0 + SG_K < p.K) k_step(av[1], bv[1], k0 + SG_K, k0 + 3 * SG_K);
     }
     // D layout: column (n) = lane & 15, row (m) = 4 * (lane >> 4) + r
 #pragma unroll

@@ -471,34 +471,55 @@ __global__ __launch_bounds__(256) void tave_temp_grad_kernel(TaveGrad p) {
     __syncthreads();
     const T* X = (const T*)p.patches + (long)unit * p.unit_stride;
     const float* pos = p.pos + (long)cam * P * D;
-    constexpr int MAXE = 16;                                   // D <= 1024: at most 16 elements of a row per lane
-    const int ne = D / 64;
-    for (int pp = wave; pp < P; pp += 4) {
-        float xv[MAXE], pv[MAXE];
-        float sq = 0.f;
+    // A wave takes NP patches at a time: every text / gradient row read from LDS (16 bytes per lane) then serves NP dot
+    // products -- one patch at a time the kernel re-read all 2 K D floats per patch and the LDS set its pace.
+    constexpr int NP = 4, NV = 4;                              // D <= 1024: at most 4 groups of 4 elements of a row per lane
+    typedef typename Half16<T>::v4 h4;
+    const int nq = D / 4;                                      // 4-element groups per row
+    for (int p0 = wave * NP; p0 < P; p0 += 4 * NP) {
+        f32x4 xv[NP][NV], pv[NP][NV];
 #pragma unroll
-        for (int e = 0; e < MAXE; ++e) {
-            xv[e] = pv[e] = 0.f;
-            if (e < ne) {
-                xv[e] = (float)X[(long)pp * D + e * 64 + lane];
-                pv[e] = pos[(long)pp * D + e * 64 + lane];
-                sq += xv[e] * xv[e];
-            }
-        }
-        const float rn = 1.0f / sqrtf(wave_sum(sq));
+        for (int j = 0; j < NP; ++j) {
+            const int pp = min(p0 + j, P - 1);                 // (patches past the end: a repeat of the last one, not stored)
+            float sq = 0.f;
 #pragma unroll
-        for (int e = 0; e < MAXE; ++e) { xv[e] *= rn; pv[e] += xv[e]; }          // xh and v = xh + pos
-        for (int k = 0; k < K; ++k) {
-            float sk = 0.f, ck = 0.f;
-#pragma unroll
-            for (int e = 0; e < MAXE; ++e)
-                if (e < ne) {
-                    sk += xv[e] * th[k * D + e * 64 + lane];
-                    ck += pv[e] * gs[k * D + e * 64 + lane];
+            for (int e = 0; e < NV; ++e) {
+                const int q = e * 64 + lane;
+                xv[j][e] = pv[j][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (q < nq) {
+                    const h4 xr = *(const h4*)(X + (long)pp * D + 4 * q);
+                    xv[j][e] = (f32x4){(float)xr[0], (float)xr[1], (float)xr[2], (float)xr[3]};
+                    pv[j][e] = *(const f32x4*)(pos + (long)pp * D + 4 * q);
+                    sq += xv[j][e][0] * xv[j][e][0] + xv[j][e][1] * xv[j][e][1] + xv[j][e][2] * xv[j][e][2] + xv[j][e][3] * xv[j][e][3];
                 }
-            sk = wave_sum(sk);
-            ck = wave_sum(ck);
-            if (lane == 0) { sv[k * P + pp] = sk; cv[k * P + pp] = ck; }
+            }
+            const float rn = 1.0f / sqrtf(wave_sum(sq));
+#pragma unroll
+            for (int e = 0; e < NV; ++e) { xv[j][e] *= rn; pv[j][e] += xv[j][e]; }          // xh and v = xh + pos
+        }
+        for (int k = 0; k < K; ++k) {
+            f32x4 t4[NV], g4[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                const int q = e * 64 + lane;
+                t4[e] = g4[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (q < nq) {
+                    t4[e] = *(const f32x4*)(th + k * D + 4 * q);
+                    g4[e] = *(const f32x4*)(gs + k * D + 4 * q);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                float sk = 0.f, ck = 0.f;
+#pragma unroll
+                for (int e = 0; e < NV; ++e) {
+                    sk += xv[j][e][0] * t4[e][0] + xv[j][e][1] * t4[e][1] + xv[j][e][2] * t4[e][2] + xv[j][e][3] * t4[e][3];
+                    ck += pv[j][e][0] * g4[e][0] + pv[j][e][1] * g4[e][1] + pv[j][e][2] * g4[e][2] + pv[j][e][3] * g4[e][3];
+                }
+                sk = wave_sum(sk);
+                ck = wave_sum(ck);
+                if (lane == 0 && p0 + j < P) { sv[k * P + p0 + j] = sk; cv[k * P + p0 + j] = ck; }
+            }
         }
     }
     __syncthreads();
@@ -670,6 +691,8 @@ extern "C" int otter_text_aware_pool_temperature_grad(int dtype, const void* pat
     OTTER_REQUIRE(n_obs > 0 && cams > 0 && t_rep > 0 && n_obs % t_rep == 0 && P > 0 && D > 0 && K > 0, OTTER_ERR_INVALID_ARGUMENT,
                   "otter_text_aware_pool_temperature_grad: bad sizes");
     OTTER_REQUIRE(D % 64 == 0 && D <= 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_temperature_grad: D=%d must be a multiple of 64, at most 1024", D);
+    OTTER_REQUIRE(unit_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(patches) & 7u) == 0 && aligned16(pos), OTTER_ERR_ALIGNMENT,
+                  "otter_text_aware_pool_temperature_grad: patches must be 8-byte aligned with unit_stride a multiple of 4, pos 16-byte aligned");
     const size_t lds = sizeof(float) * ((size_t)2 * K * D + (size_t)2 * K * P + K);
     OTTER_REQUIRE(lds <= 160 * 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_temperature_grad: needs %zu bytes of LDS", lds);
     TaveGrad a{patches, unit_stride, dtype == DT_F16, text, pos, temperature, grad_out, partial, cams, P, D, K, t_rep, n_obs};

@@ -26,7 +26,8 @@ def _randn(seed, *shape):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
 
 
-@pytest.mark.parametrize("m,n,k", [(192, 768, 768), (5, 120, 1536), (70, 33, 17), (1, 64, 10), (300, 2304, 704)])
+@pytest.mark.parametrize("m,n,k", [(192, 768, 768), (5, 120, 1536), (70, 33, 17), (1, 64, 10), (300, 2304, 704),
+                                   (2880, 768, 100), (40, 24, 130), (2900, 700, 64)])   # 64x64 tiles (>= 512 of them), ragged K steps
 def test_sgemm_all_transposes(dev, m, n, k):
     from otter_amd import ops
     a, b, bias = _randn(1, m, k), _randn(2, n, k) / math.sqrt(k), _randn(3, n)
@@ -40,7 +41,7 @@ def test_sgemm_all_transposes(dev, m, n, k):
     torch.testing.assert_close(dx.cpu().double(), 0.5 + dy.double() @ b.double(), rtol=1e-5, atol=1e-5)
     dw = torch.zeros(n, k, device=dev)
     ops.sgemm(dy.to(dev), a.to(dev), dw, trans_a=True, accumulate=True)                     # weight gradient dy^T x
-    torch.testing.assert_close(dw.cpu().double(), dy.double().t() @ a.double(), rtol=1e-5, atol=1e-4)   # fp32 sums of up to 300 O(1) products
+    torch.testing.assert_close(dw.cpu().double(), dy.double().t() @ a.double(), rtol=1e-5, atol=1e-4 * max(1.0, m / 300))   # fp32 sums of m O(1) products
     # strided views: a column slice as output, a wider buffer as input
     wide = torch.zeros(m, n + 16, device=dev)
     ops.sgemm(a.to(dev), b.to(dev), wide[:, 8:8 + n], trans_b=True)

@@ -159,9 +159,10 @@ def test_adamw_matches_torch(dev):
     assert torch.equal(p, before)                                    # non-finite gradients: the step is skipped
 
 
-def test_temperature_gradient(dev):
+@pytest.mark.parametrize("p,d", [(64, 128), (50, 768), (37, 1024)])      # rows narrower than a wave's 256 elements; patch counts that are no multiple of 4
+def test_temperature_gradient(dev, p, d):
     from otter_amd import ops
-    m, cams, p, d, k = 3, 2, 64, 128, 15
+    m, cams, k = 3, 2, 15
     patches = _randn(18, m * cams, p + 1, d).half()
     text = _randn(19, m, k, d)
     pos = _randn(20, cams, p, d) * 0.5

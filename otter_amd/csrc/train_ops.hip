@@ -28,19 +28,30 @@ constexpr int SG_K = 64;
 
 // The problems of the trainable tail are small (192 tokens x 768 columns), and fp32 MFMA gives a CU only ~0.6 TFLOP/s, so a
 // launch must spread over as many CUs as it can: T = 32 (one 16x16 MFMA tile per wave) when 64x64 tiles would number fewer
-// than two per CU, T = 64 (2x2 per wave) otherwise.  A launch is then a short chain of K-steps each waiting for its
-// operands: two K-steps of 64 are kept in flight in registers (the loads of K-step s+2 are requested as soon as K-step s has
-// been copied to LDS), and every per-element index, offset and row / column bound is computed once, ahead of the loop.
-template <int T>
+// than two per CU, T = 64 (2x2 per wave) otherwise.  A launch is then a short chain of K-steps:
+//  * two K-steps of 64 are kept in flight in registers (the loads of K-step s+2 are requested as soon as K-step s has been
+//    copied to LDS), so no K-step waits for memory;
+//  * an operand tile lies in LDS with the index that is contiguous in MEMORY contiguous in LDS too -- [m][k] (pitch LDK) for
+//    a k-contiguous operand (AK / !BN), [k][m] (pitch LD) for an m-contiguous one: the threads copy consecutive memory
+//    elements to consecutive banks, and both pitches are 4 mod 32, which keeps the MFMA operand reads (16 lanes along one
+//    index, 4 along the other) conflict-free in either layout.  The layouts are template parameters, so every LDS offset of
+//    the product phase is an immediate;
+//  * VEC: 16-byte loads and LDS writes along the contiguous index when strides, extents and pointers allow (4x fewer
+//    instructions in the two copy phases, which were half of a K-step);
+//  * the product phase first requests all fragments of the K-step, then issues its MFMAs back to back.
+template <int T, bool AK, bool BN, bool VEC>
 __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
-    constexpr int LD = T + 4, E = T * SG_K / 256, R = T / 32;      // E elements of each operand tile per thread and K-step
-    __shared__ float As[SG_K][LD];        // [k][m]
-    __shared__ float Bs[SG_K][LD];        // [k][n]
+    constexpr int LD = T + 4, LDK = SG_K + 4, R = T / 32;
+    constexpr int G = VEC ? 4 : 1;                                  // elements per copy instruction
+    constexpr int E = T * SG_K / 256 / G;                           // copy instructions per operand, thread and K-step
+    constexpr int TILE_F = (SG_K * LD > T * LDK) ? SG_K * LD : T * LDK;
+    typedef float cp_t __attribute__((ext_vector_type(G)));
+    __shared__ __attribute__((aligned(16))) float As[TILE_F];
+    __shared__ __attribute__((aligned(16))) float Bs[TILE_F];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int wm = wave & 1, wn = wave >> 1;
     const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
-    const bool a_kfast = p.sak == 1, b_nfast = p.sbn == 1;
 
     f32x4 acc[R][R];
 #pragma unroll
@@ -48,71 +59,80 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
 #pragma unroll
         for (int j = 0; j < R; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // element i of this thread in a tile: the thread order follows whichever index is contiguous in memory
+    // copy instruction i of this thread: G consecutive elements along the operand's contiguous index.  Rows / columns past
+    // the edge read a clamped address (they only feed outputs that are never stored).
     int ka[E], kb[E], lds_a[E], lds_b[E];
     long off_a[E], off_b[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         const int e = tid + 256 * i;
         int k, m, k2, n;
-        if (a_kfast) { k = e % SG_K; m = e / SG_K; } else { m = e % T; k = e / T; }
-        if (b_nfast) { n = e % T; k2 = e / T; } else { k2 = e % SG_K; n = e / SG_K; }
+        if (AK) { k = (e % (SG_K / G)) * G; m = e / (SG_K / G); } else { m = (e % (T / G)) * G; k = e / (T / G); }
+        if (BN) { n = (e % (T / G)) * G; k2 = e / (T / G); } else { k2 = (e % (SG_K / G)) * G; n = e / (SG_K / G); }
         ka[i] = k; kb[i] = k2;
-        lds_a[i] = k * LD + m; lds_b[i] = k2 * LD + n;
-        off_a[i] = (long)min(m0 + m, p.M - 1) * p.sam + (long)k * p.sak;      // rows / columns past the edge: any address in bounds
-        off_b[i] = (long)k2 * p.sbk + (long)min(n0 + n, p.N - 1) * p.sbn;
+        lds_a[i] = AK ? m * LDK + k : k * LD + m;
+        lds_b[i] = BN ? k2 * LD + n : n * LDK + k2;
+        off_a[i] = (long)min(m0 + m, p.M - (AK ? 1 : G)) * p.sam + (long)k * p.sak;
+        off_b[i] = (long)k2 * p.sbk + (long)min(n0 + n, p.N - (BN ? G : 1)) * p.sbn;
     }
-    float av[2][E], bv[2][E];              // two K-steps in flight
+    // MFMA operand reads: A element (k = 4 kk + g, m = this wave's rows + 16 i + li), B likewise with n
+    const int rd_a = AK ? (wm * (T / 2) + li) * LDK + g : g * LD + wm * (T / 2) + li;
+    const int rd_b = BN ? g * LD + wn * (T / 2) + li : (wn * (T / 2) + li) * LDK + g;
+    constexpr int A_KK = AK ? 4 : 4 * LD, A_I = AK ? 16 * LDK : 16;       // offsets per kk and per 16-row tile
+    constexpr int B_KK = BN ? 4 * LD : 4, B_J = BN ? 16 : 16 * LDK;
+
+    cp_t av[2][E], bv[2][E];              // two K-steps in flight
     // Every load is unconditional (a load inside a branch would make the compiler drain the whole queue at its first use, and
-    // with it the K-step requested behind): out-of-range elements read a clamped address.
-    auto fetch = [&](float (&a)[E], float (&b)[E], int k0) {
+    // with it the K-step requested behind): in the ragged last K-step (and in the dummy requests past it, which keep the
+    // request count the same on every path) k is clamped.
+    auto fetch = [&](cp_t (&a)[E], cp_t (&b)[E], int k0) {
         const float* Ak = p.A + (long)k0 * p.sak;
         const float* Bk = p.B + (long)k0 * p.sbk;
         if (k0 + SG_K <= p.K) {
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                a[i] = Ak[off_a[i]];
-                b[i] = Bk[off_b[i]];
-            }
-        } else {                          // the ragged last K-step: same number of requests, k clamped to K - 1
-#pragma unroll
-            for (int i = 0; i < E; ++i) {
-                a[i] = Ak[off_a[i] + (long)(min(k0 + ka[i], p.K - 1) - (k0 + ka[i])) * p.sak];
-                b[i] = Bk[off_b[i] + (long)(min(k0 + kb[i], p.K - 1) - (k0 + kb[i])) * p.sbk];
-            }
-        }
-    };
-    auto k_step = [&](float (&a)[E], float (&b)[E], int k0, int k_next) {
-        __syncthreads();                  // previous K-step's fragments have been read
-        // (rows / columns past the edge only feed outputs that are never stored; elements past K must be zero)
-        if (k0 + SG_K <= p.K) {
-#pragma unroll
-            for (int i = 0; i < E; ++i) {
-                (&As[0][0])[lds_a[i]] = a[i];
-                (&Bs[0][0])[lds_b[i]] = b[i];
+                a[i] = *(const cp_t*)(Ak + off_a[i]);
+                b[i] = *(const cp_t*)(Bk + off_b[i]);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                (&As[0][0])[lds_a[i]] = k0 + ka[i] < p.K ? a[i] : 0.f;
-                (&Bs[0][0])[lds_b[i]] = k0 + kb[i] < p.K ? b[i] : 0.f;
+                a[i] = *(const cp_t*)(Ak + off_a[i] + (long)(min(k0 + ka[i], p.K - (AK ? G : 1)) - (k0 + ka[i])) * p.sak);
+                b[i] = *(const cp_t*)(Bk + off_b[i] + (long)(min(k0 + kb[i], p.K - (BN ? 1 : G)) - (k0 + kb[i])) * p.sbk);
+            }
+        }
+    };
+    auto k_step = [&](cp_t (&a)[E], cp_t (&b)[E], int k0, int k_next) {
+        __syncthreads();                  // previous K-step's fragments have been read
+        if (k0 + SG_K <= p.K) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                *(cp_t*)(As + lds_a[i]) = a[i];
+                *(cp_t*)(Bs + lds_b[i]) = b[i];
+            }
+        } else {                          // elements past K must be zero (a VEC group along k lies wholly inside or outside: K % 4 == 0)
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                *(cp_t*)(As + lds_a[i]) = k0 + ka[i] < p.K ? a[i] : (cp_t)(0.f);
+                *(cp_t*)(Bs + lds_b[i]) = k0 + kb[i] < p.K ? b[i] : (cp_t)(0.f);
             }
         }
         __syncthreads();
-        fetch(a, b, k_next);              // two K-steps ahead, into the registers just copied out (past the end of K: clamped
-                                          // dummy requests -- a request count that varied by path would again cost a drain)
+        fetch(a, b, k_next);              // two K-steps ahead, into the registers just copied out
+        float fa[SG_K / 4][R], fb[SG_K / 4][R];
 #pragma unroll
         for (int kk = 0; kk < SG_K / 4; ++kk) {
-            float fa[R], fb[R];
 #pragma unroll
-            for (int i = 0; i < R; ++i) fa[i] = As[kk * 4 + g][wm * (T / 2) + i * 16 + li];
+            for (int i = 0; i < R; ++i) fa[kk][i] = As[rd_a + kk * A_KK + i * A_I];
 #pragma unroll
-            for (int j = 0; j < R; ++j) fb[j] = Bs[kk * 4 + g][wn * (T / 2) + j * 16 + li];
+            for (int j = 0; j < R; ++j) fb[kk][j] = Bs[rd_b + kk * B_KK + j * B_J];
+        }
+#pragma unroll
+        for (int kk = 0; kk < SG_K / 4; ++kk)
 #pragma unroll
             for (int i = 0; i < R; ++i)
 #pragma unroll
-                for (int j = 0; j < R; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < R; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
     };
     if (p.K > 0) {
         fetch(av[0], bv[0], 0);
@@ -562,8 +582,21 @@ extern "C" int otter_sgemm_strided(const float* A, long sa_m, long sa_k, const f
     const int t = small ? 32 : 64;
     dim3 grid((N + t - 1) / t, (M + t - 1) / t);
     OTTER_REQUIRE(grid.y < 65536, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_sgemm_strided: M=%d too large", M);
-    if (small) hipLaunchKernelGGL(sgemm_strided_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(sgemm_strided_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    // layouts: which index of each operand is contiguous in memory (an operand with neither stride 1 takes the scalar
+    // "m / n contiguous" form, which is correct for any strides)
+    const bool ak = sa_k == 1, bn = !(sb_k == 1);
+    auto mult4 = [](long v) { return (v & 3) == 0; };
+    const bool vec = aligned16(A) && aligned16(B) && (ak ? mult4(sa_m) && mult4(K) : sa_m == 1 && mult4(sa_k) && mult4(M)) &&
+                     (bn ? sb_n == 1 && mult4(sb_k) && mult4(N) : mult4(sb_n) && mult4(K));
+    hipStream_t st = (hipStream_t)stream;
+#define OTTER_SG_LAUNCH(T_, AK_, BN_, V_) hipLaunchKernelGGL((sgemm_strided_kernel<T_, AK_, BN_, V_>), grid, dim3(256), 0, st, a)
+#define OTTER_SG_PICK_V(T_, AK_, BN_) do { if (vec) OTTER_SG_LAUNCH(T_, AK_, BN_, true); else OTTER_SG_LAUNCH(T_, AK_, BN_, false); } while (0)
+#define OTTER_SG_PICK_L(T_) do { if (ak && bn) OTTER_SG_PICK_V(T_, true, true); else if (ak) OTTER_SG_PICK_V(T_, true, false); \
+                                 else if (bn) OTTER_SG_PICK_V(T_, false, true); else OTTER_SG_PICK_V(T_, false, false); } while (0)
+    if (small) OTTER_SG_PICK_L(32); else OTTER_SG_PICK_L(64);
+#undef OTTER_SG_PICK_L
+#undef OTTER_SG_PICK_V
+#undef OTTER_SG_LAUNCH
     OTTER_CHECK_LAUNCH("otter_sgemm_strided");
     return OTTER_OK;
 }

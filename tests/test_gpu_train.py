@@ -27,7 +27,7 @@ def _randn(seed, *shape):
 
 
 @pytest.mark.parametrize("m,n,k", [(192, 768, 768), (5, 120, 1536), (70, 33, 17), (1, 64, 10), (300, 2304, 704),
-                                   (2880, 768, 100), (40, 24, 130), (2900, 700, 64)])   # 64x64 tiles (>= 512 of them), ragged K steps
+                                   (2880, 768, 100), (40, 24, 130), (2900, 700, 64), (2881, 769, 65)])   # 64x64 tiles (>= 512 of them), ragged K steps, extents that rule out 16-byte copies
 def test_sgemm_all_transposes(dev, m, n, k):
     from otter_amd import ops
     a, b, bias = _randn(1, m, k), _randn(2, n, k) / math.sqrt(k), _randn(3, n)

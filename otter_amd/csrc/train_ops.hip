@@ -12,8 +12,8 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------------------------
 // C[M,N] (+)= op(A)[M,K] . op(B)[K,N] (+ bias[n]),  A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn].
-// One workgroup = 64x64 output tile, 4 waves of 32x32 (2x2 v_mfma_f32_16x16x4_f32 tiles), K-step 32 through LDS with the
-// next step's operands prefetched into registers.
+// One workgroup (4 waves) = one 64x64 or 32x32 output tile on v_mfma_f32_16x16x4_f32, K-steps of 64 through LDS with the
+// operands of the next two steps in flight in registers (see sgemm_strided_kernel).
 // Used for the forward (x W^T), the input gradient (dy W) and the weight gradient (dy^T x) of every linear layer,
 // straight from the parameter storage (no packed copies to refresh after an optimizer step).
 struct SGemm {

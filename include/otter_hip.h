@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 10
+#define OTTER_HIP_ABI_VERSION 11
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -197,9 +197,11 @@ int otter_window_append(const float* src, const float* fresh, float* dst, const 
 
 /* C[M,N] (+)= op(A)[M,K] . op(B)[K,N] (+ bias[n]) with element strides: A(m,k) = A[m*sa_m + k*sa_k],
  * B(k,n) = B[k*sb_k + n*sb_n].  nn.Linear forward (transformer.py:38-50, models.py:42-66): A = x, B = W^T
- * (sb_k = 1, sb_n = ldw); input gradient dy.W: sb_k = ldw, sb_n = 1; weight gradient dy^T.x: sa_m = 1, sa_k = ld_dy. */
+ * (sb_k = 1, sb_n = ldw); input gradient dy.W: sb_k = ldw, sb_n = 1; weight gradient dy^T.x: sa_m = 1, sa_k = ld_dy.
+ * a_rowsum (may be NULL): [M] floats that receive (+= with accumulate) sum_k A(m, k) -- with A = dy^T the bias gradient,
+ * from the same launch as the weight gradient. */
 int otter_sgemm_strided(const float* A, long sa_m, long sa_k, const float* B, long sb_k, long sb_n, const float* bias,
-                        float* C, long ldc, int M, int N, int K, int accumulate, void* stream);
+                        float* C, long ldc, int M, int N, int K, int accumulate, float* a_rowsum, void* stream);
 
 /* y = act(z) and dz += dy * act'(z); act: OTTER_EPI_ACT_* (nn.GELU of transformer.py:75-79 / timm Mlp, nn.ReLU of models.py:42-66). */
 int otter_act_fwd(const float* z, float* y, long n, int act, void* stream);

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
@@ -57,7 +57,7 @@ _SIGNATURES = {
     "otter_resize_bicubic_u8": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     "otter_action_step": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, c_double, _P],
     # training step
-    "otter_sgemm_strided": [_P, _L, _L, _P, _L, _L, _P, _P, _L, _I, _I, _I, _I, _P],
+    "otter_sgemm_strided": [_P, _L, _L, _P, _L, _L, _P, _P, _L, _I, _I, _I, _I, _P, _P],
     "otter_act_fwd": [_P, _P, _L, _I, _P],
     "otter_act_bwd": [_P, _P, _P, _L, _I, _P],
     "otter_col_sum": [_P, _L, _P, _L, _I, _I, _P, _I, _P],

@@ -22,6 +22,7 @@ struct SGemm {
     const float* bias;
     float* C; long ldc;
     int M, N, K, accumulate;
+    float* a_rowsum;            // [M] or null: (+)= sum_k A(m, k) -- the bias gradient beside a weight gradient dy^T . x
 };
 
 constexpr int SG_K = 64;
@@ -38,7 +39,9 @@ constexpr int SG_K = 64;
 //    the product phase is an immediate;
 //  * VEC: 16-byte loads and LDS writes along the contiguous index when strides, extents and pointers allow (4x fewer
 //    instructions in the two copy phases, which were half of a K-step);
-//  * the product phase first requests all fragments of the K-step, then issues its MFMAs back to back.
+//  * the product phase first requests all fragments of the K-step, then issues its MFMAs back to back;
+//  * a_rowsum: the workgroups of the first column tile also add up the rows of their A tiles from LDS (T/4 elements per
+//    thread and K-step), which saves the weight-gradient call of a linear layer its separate column-sum launch for the bias.
 template <int T, bool AK, bool BN, bool VEC>
 __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
     constexpr int LD = T + 4, LDK = SG_K + 4, R = T / 32;
@@ -81,6 +84,9 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
     constexpr int A_KK = AK ? 4 : 4 * LD, A_I = AK ? 16 * LDK : 16;       // offsets per kk and per 16-row tile
     constexpr int B_KK = BN ? 4 * LD : 4, B_J = BN ? 16 : 16 * LDK;
 
+    const bool do_rs = p.a_rowsum != nullptr && blockIdx.x == 0;       // (uniform in the workgroup)
+    const int rs_m = tid % T, rs_kq = tid / T;                          // row and K slice (of 256 / T) this thread adds up
+    float rs = 0.f;
     cp_t av[2][E], bv[2][E];              // two K-steps in flight
     // Every load is unconditional (a load inside a branch would make the compiler drain the whole queue at its first use, and
     // with it the K-step requested behind): in the ragged last K-step (and in the dummy requests past it, which keep the
@@ -119,6 +125,13 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
         }
         __syncthreads();
         fetch(a, b, k_next);              // two K-steps ahead, into the registers just copied out
+        if (do_rs) {
+#pragma unroll
+            for (int j = 0; j < T / 4; ++j) {
+                const int k = rs_kq * (T / 4) + j;
+                rs += AK ? As[rs_m * LDK + k] : As[k * LD + rs_m];
+            }
+        }
         float fa[SG_K / 4][R], fb[SG_K / 4][R];
 #pragma unroll
         for (int kk = 0; kk < SG_K / 4; ++kk) {
@@ -141,6 +154,18 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(SGemm p) {
     for (int k0 = 0; k0 < p.K; k0 += 2 * SG_K) {
         k_step(av[0], bv[0], k0, k0 + 2 * SG_K);
         if (k0 + SG_K < p.K) k_step(av[1], bv[1], k0 + SG_K, k0 + 3 * SG_K);
+    }
+    if (do_rs) {
+        __syncthreads();                  // the last K-step's fragments have been read: As is free
+        As[rs_kq * T + rs_m] = rs;
+        __syncthreads();
+        if (tid < T && m0 + tid < p.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 256 / T; ++q) t += As[q * T + tid];
+            float* dst = p.a_rowsum + m0 + tid;
+            *dst = p.accumulate ? *dst + t : t;
+        }
     }
     // D layout: column (n) = lane & 15, row (m) = 4 * (lane >> 4) + r
 #pragma unroll
@@ -573,11 +598,11 @@ __global__ __launch_bounds__(256) void tave_temp_grad_kernel(TaveGrad p) {
 
 // ==================================================================================================================
 extern "C" int otter_sgemm_strided(const float* A, long sa_m, long sa_k, const float* B, long sb_k, long sb_n, const float* bias,
-                                   float* C, long ldc, int M, int N, int K, int accumulate, void* stream) {
+                                   float* C, long ldc, int M, int N, int K, int accumulate, float* a_rowsum, void* stream) {
     OTTER_REQUIRE(A && B && C, OTTER_ERR_INVALID_ARGUMENT, "otter_sgemm_strided: null operand");
     if (M == 0 || N == 0) return OTTER_OK;
     OTTER_REQUIRE(M > 0 && N > 0 && K >= 0 && ldc >= N, OTTER_ERR_INVALID_ARGUMENT, "otter_sgemm_strided: bad sizes M=%d N=%d K=%d ldc=%ld", M, N, K, ldc);
-    SGemm a{A, sa_m, sa_k, B, sb_k, sb_n, bias, C, ldc, M, N, K, accumulate ? 1 : 0};
+    SGemm a{A, sa_m, sa_k, B, sb_k, sb_n, bias, C, ldc, M, N, K, accumulate ? 1 : 0, a_rowsum};
     const bool small = (long)((N + 63) / 64) * ((M + 63) / 64) < 512;      // fewer than two 64x64 tiles per CU: 32x32 tiles (the fp32 MFMA rate of the busy CUs is the bound)
     const int t = small ? 32 : 64;
     dim3 grid((N + t - 1) / t, (M + t - 1) / t);

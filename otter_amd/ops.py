@@ -504,8 +504,9 @@ def _f32_2d(t: Tensor, name: str):
 
 
 def sgemm(a: Tensor, b: Tensor, out: Tensor, *, trans_a: bool = False, trans_b: bool = False, bias: Optional[Tensor] = None,
-          accumulate: bool = False) -> Tensor:
-    """out (+)= op(a) @ op(b) (+ bias), fp32, 2-D row-major views with arbitrary row strides (no packing)."""
+          accumulate: bool = False, a_rowsum: Optional[Tensor] = None) -> Tensor:
+    """out (+)= op(a) @ op(b) (+ bias), fp32, 2-D row-major views with arbitrary row strides (no packing).
+    ``a_rowsum`` (fp32, M elements, contiguous): also (+)= the row sums of op(a) -- the bias gradient when op(a) = dy^T."""
     ra, ca, lda = _f32_2d(a, "sgemm.a")
     rb, cb, ldb = _f32_2d(b, "sgemm.b")
     m, k = (ca, ra) if trans_a else (ra, ca)
@@ -519,7 +520,12 @@ def sgemm(a: Tensor, b: Tensor, out: Tensor, *, trans_a: bool = False, trans_b: 
             raise ValueError("sgemm: bias length mismatch")
     sam, sak = (1, lda) if trans_a else (lda, 1)
     sbk, sbn = (1, ldb) if trans_b else (ldb, 1)
-    _lib.call("otter_sgemm_strided", _ptr(a), sam, sak, _ptr(b), sbk, sbn, _ptr(bias), _ptr(out), ldc, m, n, k, int(accumulate), _stream())
+    if a_rowsum is not None:
+        _chk(a_rowsum, torch.float32, "sgemm.a_rowsum", 1)
+        if a_rowsum.numel() != m or not a_rowsum.is_contiguous():
+            raise ValueError("sgemm: a_rowsum must be a contiguous vector of M elements")
+    _lib.call("otter_sgemm_strided", _ptr(a), sam, sak, _ptr(b), sbk, sbn, _ptr(bias), _ptr(out), ldc, m, n, k, int(accumulate),
+              _ptr(a_rowsum), _stream())
     return out
 
 

@@ -64,9 +64,10 @@ def linear(tape: Tape, x: Var, w: Var, b: Optional[Var], out: Optional[Var] = No
         if out.g is None:
             return
         dy = out.g
-        if w.needs_grad:
-            ops.sgemm(dy, x.t, w.grad(), trans_a=True, accumulate=True)
-        if b is not None and b.needs_grad:
+        db = b is not None and b.needs_grad
+        if w.needs_grad:                                   # the bias gradient (column sums of dy) rides on the same launch
+            ops.sgemm(dy, x.t, w.grad(), trans_a=True, accumulate=True, a_rowsum=b.grad() if db else None)
+        elif db:
             ops.col_sum(dy, b.grad(), accumulate=True)
         if x.needs_grad:
             ops.sgemm(dy, w.t, x.grad(), accumulate=True)

@@ -40,7 +40,9 @@ def test_sgemm_all_transposes(dev, m, n, k):
     ops.sgemm(dy.to(dev), b.to(dev), dx, accumulate=True)                                  # input gradient, accumulated
     torch.testing.assert_close(dx.cpu().double(), 0.5 + dy.double() @ b.double(), rtol=1e-5, atol=1e-5)
     dw = torch.zeros(n, k, device=dev)
-    ops.sgemm(dy.to(dev), a.to(dev), dw, trans_a=True, accumulate=True)                     # weight gradient dy^T x
+    db = torch.full((n,), 0.25, device=dev)
+    ops.sgemm(dy.to(dev), a.to(dev), dw, trans_a=True, accumulate=True, a_rowsum=db)        # weight gradient dy^T x, bias gradient beside it
+    torch.testing.assert_close(db.cpu().double(), 0.25 + dy.double().sum(0), rtol=1e-5, atol=1e-4 * max(1.0, m / 300))
     torch.testing.assert_close(dw.cpu().double(), dy.double().t() @ a.double(), rtol=1e-5, atol=1e-4 * max(1.0, m / 300))   # fp32 sums of m O(1) products
     # strided views: a column slice as output, a wider buffer as input
     wide = torch.zeros(m, n + 16, device=dev)

@@ -277,12 +277,31 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* x, long
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     float sg = 0.f, sb = 0.f;
-    if (c < width)
-        for (int r = rg; r < rows; r += 16) {
+    if (c < width) {
+        // four rows per pass, their loads requested together: one row per pass made the loop a chain of memory round trips
+        int r = rg;
+        for (; r + 48 < rows; r += 64) {
+            float d[4], xv[4], mu[4], rs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + 16 * u;
+                d[u] = dy[(long)ru * ldy + c];
+                xv[u] = x[(long)ru * ldx + c];
+                mu[u] = stats[2 * ru];
+                rs[u] = stats[2 * ru + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sg += d[u] * (xv[u] - mu[u]) * rs[u];
+                sb += d[u];
+            }
+        }
+        for (; r < rows; r += 16) {
             const float d = dy[(long)r * ldy + c];
             sg += d * (x[(long)r * ldx + c] - stats[2 * r]) * stats[2 * r + 1];
             sb += d;
         }
+    }
     pg[rg][cl] = sg;
     pb[rg][cl] = sb;
     __syncthreads();

@@ -14,6 +14,7 @@ and a residual connection hands its output-gradient buffer on to the skip input 
 """
 from __future__ import annotations
 
+import threading
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -21,6 +22,30 @@ import torch
 from . import ops
 
 Tensor = torch.Tensor
+
+
+class _GradArena:
+    """Activation-gradient buffers of one forward + backward pass, carved out of ONE zero-filled allocation (about 150 separate
+    zero fills per pass otherwise, each a launch).  The size is learnt from the previous pass; whatever does not fit falls
+    back to its own allocation."""
+
+    def __init__(self, device, hint: int):
+        self.buf = torch.zeros(hint, dtype=torch.float32, device=device) if hint > 0 else None
+        self.off = 0          # elements handed out of ``buf``
+        self.used = 0         # elements asked for in all (the next pass's hint)
+
+    def take(self, like: Tensor) -> Tensor:
+        n = like.numel()
+        n_al = (n + 63) // 64 * 64
+        self.used += n_al
+        if self.buf is not None and like.device == self.buf.device and self.off + n_al <= self.buf.numel():
+            out = self.buf[self.off:self.off + n].view(like.shape)
+            self.off += n_al
+            return out
+        return torch.zeros_like(like, memory_format=torch.contiguous_format)
+
+
+_arena_tls = threading.local()
 
 
 class Var:
@@ -33,7 +58,11 @@ class Var:
 
     def grad(self) -> Tensor:
         if self.g is None:
-            self.g = torch.zeros_like(self.t, memory_format=torch.contiguous_format)
+            arena = getattr(_arena_tls, "arena", None)
+            if arena is not None and self.t.dtype == torch.float32:
+                self.g = arena.take(self.t)
+            else:
+                self.g = torch.zeros_like(self.t, memory_format=torch.contiguous_format)
         return self.g
 
 
@@ -239,6 +268,18 @@ class TrainableTail:
         """images (B, T, cams, 3, R, R) uint8 / fp32 on the device; tokens (B, ctx) int32 on the host; proprio (B, T, P_in);
         gt_actions (B, T, horizon, action_dim).  With ``grads`` (name -> zero-initialised fp32 buffer) the gradients of
         ``grad_scale * loss`` are accumulated into it.  Returns the loss as a (1,) device tensor."""
+        if grads is None:
+            return self._forward_backward(images, tokens_host, proprio, gt_actions, text_mask, grads, grad_scale)
+        arena = _GradArena(images.device, getattr(self, "_arena_hint", 0))
+        _arena_tls.arena = arena
+        try:
+            return self._forward_backward(images, tokens_host, proprio, gt_actions, text_mask, grads, grad_scale)
+        finally:
+            _arena_tls.arena = None
+            self._arena_hint = arena.used
+
+    def _forward_backward(self, images: Tensor, tokens_host: Tensor, proprio: Tensor, gt_actions: Tensor, text_mask: Optional[Tensor],
+                          grads: Optional[Dict[str, Tensor]], grad_scale: float = 1.0) -> Tensor:
         model = self.model
         clip = model.clip_device()
         dm = self._dims(clip.device, clip.dtype)

@@ -43,13 +43,14 @@ def kernel_sources_sha256() -> str:
 
 
 def pmc_counters_of_this_kernel():
-    """(traffic bytes per launch, MFMA-busy fraction, source tag) from the newest profiles/*_gemm_traffic.json -- the PMC
-    passes of this same command, collected by scripts/collect_profiles.sh -- or (None, None, reason) when that file was
+    """(traffic bytes per launch, MFMA-busy fraction, graphics clock in GHz, source tag) from the newest
+    profiles/*_gemm_traffic.json -- the PMC passes of this same command, collected by scripts/collect_profiles.sh -- or
+    (None, None, None, reason) when that file was
     made from other kernel sources than the ones in this tree (the counters cannot be collected inside an un-profiled run)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))
     if not files:
-        return None, None, "no profiles/*_gemm_traffic.json"
+        return None, None, None, "no profiles/*_gemm_traffic.json"
     path = files[-1]
     try:
         with open(path) as fh:
@@ -57,11 +58,11 @@ def pmc_counters_of_this_kernel():
         if pmc.get("kernel_sources_sha256") != kernel_sources_sha256():
             print(f"bench: {os.path.basename(path)} was collected from other GEMM sources than this tree's: roofline.traffic left null "
                   "(re-run scripts/collect_profiles.sh)", file=sys.stderr)
-            return None, None, f"profiles/{os.path.basename(path)} is stale (kernel sources changed since it was collected)"
-        return pmc["traffic_bytes_per_launch"], pmc.get("mfma_busy_fraction_of_simd_cycles"), \
+            return None, None, None, f"profiles/{os.path.basename(path)} is stale (kernel sources changed since it was collected)"
+        return pmc["traffic_bytes_per_launch"], pmc.get("mfma_busy_fraction_of_simd_cycles"), pmc.get("gfx_clock_ghz_in_kernel"), \
             f"profiles/{os.path.basename(path)} (rocprofv3 --pmc passes of this command; kernel sources sha256 {pmc['kernel_sources_sha256'][:12]})"
     except (OSError, KeyError, ValueError) as exc:
-        return None, None, f"unreadable counter file: {exc}"
+        return None, None, None, f"unreadable counter file: {exc}"
 
 
 def build_model(device, seed=0, clip_dtype=torch.float16):
@@ -416,11 +417,14 @@ def main():
             tf = gm["total_work"] / (gm["total_ms"] * 1e-3) / 1e12
             # hardware counters cannot be read from inside an un-profiled run: quoted from the PMC passes of this same
             # command, and only while the kernel sources are the ones those passes ran (else null)
-            traffic, mfma_busy, pmc_source = pmc_counters_of_this_kernel()
+            traffic, mfma_busy, pmc_clock, pmc_source = pmc_counters_of_this_kernel()
             result["roofline"] = {"bound": "mfma", "kernel": "gemm_256x256 (16-bit operands, CLIP towers; whole 256-row tiles)", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
                                   "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": traffic,
                                   "traffic_source": pmc_source,
                                   "algorithmic_bytes_per_launch": gm["total_bytes"] / gm["launches"], "pmc_mfma_busy_frac": mfma_busy,
+                                  # graphics clock inside the kernel by the same counter pass (cycles of the dispatch / its duration);
+                                  # `peak` is the nominal figure at the 2.4 GHz boost clock
+                                  "pmc_gfx_clock_ghz": pmc_clock,
                                   "launches": gm["launches"], "avg_launch_us": 1e3 * gm["total_ms"] / gm["launches"],
                                   "gemm_ms_per_step": gm["total_ms"] / 2}
             if world == 1 and args.workload == "infer" and not args.no_reference_points:

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 11
+#define OTTER_HIP_ABI_VERSION 12
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -159,6 +159,21 @@ typedef struct {
 int otter_readout_pool_fwd(const otter_readout_block* blocks, int n_blocks, const float* query, const float* final_ln_w,
                            const float* final_ln_b, const float* kv, long ldkv, const unsigned char* mask, float* out,
                            long ldo, int n_obs, int nk, int readouts, int d, int heads, int hidden, void* stream);
+
+/* The poolings of one encoder call in ONE launch: forward_encoder runs vision_poolings[c] for every camera and then
+ * text_pooling (otter/policy/otter.py:247,254), each an AttentionPooling with weights and sizes of its own.  A pooling
+ * is a chain of small dependent phases that takes the same ~40 us for 1 or for 256 observations, so the problems'
+ * observations are concatenated into one grid.  Fields as the arguments of otter_readout_pool_fwd; a problem with
+ * n_obs == 0 is skipped; at most 4 problems. */
+typedef struct otter_readout_problem {
+    const otter_readout_block* blocks; int n_blocks;    /* HOST array of structs holding device pointers */
+    const float* query; const float* final_ln_w; const float* final_ln_b;
+    const float* kv; long ldkv;
+    const unsigned char* mask;
+    float* out; long ldo;
+    int n_obs, nk, readouts, d, heads, hidden;
+} otter_readout_problem;
+int otter_readout_pool_fwd_multi(const otter_readout_problem* problems, int n_problems, void* stream);
 
 /* y = x / ||x||_2 per row (otter.py:195,214); x has type x_dtype (OTTER_DT_*), y is fp32. */
 int otter_l2norm_rows(int x_dtype, const void* x, long ldx, float* y, long ldy, int rows, int width, void* stream);

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
@@ -31,6 +31,14 @@ class ReadoutBlock(Structure):
         "q_ln_w", "q_ln_b", "wq_t", "bq", "wo_t", "bo", "ln_w", "ln_b", "fc1_t", "fc1_b", "fc2_t", "fc2_b")]
 
 
+class ReadoutProblem(Structure):
+    """``otter_readout_problem``: one pooling of a multi-problem readout launch."""
+    _fields_ = [("blocks", POINTER(ReadoutBlock)), ("n_blocks", c_int),
+                ("query", c_void_p), ("final_ln_w", c_void_p), ("final_ln_b", c_void_p),
+                ("kv", c_void_p), ("ldkv", c_long), ("mask", c_void_p), ("out", c_void_p), ("ldo", c_long),
+                ("n_obs", c_int), ("nk", c_int), ("readouts", c_int), ("d", c_int), ("heads", c_int), ("hidden", c_int)]
+
+
 _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
 
 _SIGNATURES = {
@@ -48,6 +56,7 @@ _SIGNATURES = {
     "otter_text_aware_pool_fwd": [_I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "otter_pos_emb_pack": [_I, _P, _P, _I, _I, _P],
     "otter_readout_pool_fwd": [POINTER(ReadoutBlock), _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "otter_readout_pool_fwd_multi": [POINTER(ReadoutProblem), _I, _P],
     "otter_l2norm_rows": [_I, _P, _L, _P, _L, _I, _I, _P],
     "otter_linear_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "otter_convert_rows": [_I, _P, _L, _P, _L, _I, _I, _I, _I, _P, _I, _I, _P],

@@ -7,6 +7,11 @@
 //               out = q1 + fc2(gelu(fc1(LN(q1))))
 //   end:        LN(out) flattened to (R*d).
 // Weights are passed transposed ([in][out]) so that consecutive threads read consecutive addresses.
+// A launch is a dependent chain of ~25 barrier-separated phases per workgroup (~40 us whatever the batch), so the
+// poolings of one encoder call -- one per camera and the text one, each with its own weights and sizes -- go into ONE
+// launch: the grid is the concatenation of the problems' observations.
+#include <algorithm>
+
 #include "common.hpp"
 #include "otter_hip.h"
 
@@ -49,10 +54,20 @@ __device__ __forceinline__ void stage_floats(float* dst, const float* src, int n
 // Weights of a cross-attention block are shared by every observation and small (d*d and d*hidden floats), so each
 // workgroup copies them into LDS in bulk -- one memory latency per matrix instead of one per inner-loop step --
 // and the matrix-vector products then run at LDS speed.
-__global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs p) {
+constexpr int MAX_PROBLEMS = 4;
+struct ReadoutMulti {
+    ReadoutArgs a[MAX_PROBLEMS];
+    int first[MAX_PROBLEMS + 1];      // problem i owns workgroups [first[i], first[i+1])
+    int n;
+};
+
+__global__ __launch_bounds__(256) void readout_kernel(ReadoutMulti mp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < mp.n && (int)blockIdx.x >= mp.first[pi + 1]) ++pi;
+    const ReadoutArgs& p = mp.a[pi];
+    const int m = blockIdx.x - mp.first[pi];
     const int R = p.R, d = p.d, nk = p.nk, heads = p.heads, hd = d / heads, hidden = p.hidden;
     const int Rd = R * d;
     float* wS = sm;                   // [2][d][d]      Wq^T | Wo^T of the current block      (16-byte aligned: first)
@@ -150,34 +165,65 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs p) {
 
 }  // namespace
 
+static size_t readout_lds_bytes(int nk, int readouts, int d, int heads, int hidden) {
+    return sizeof(float) * ((size_t)2 * d * d + (size_t)d * hidden + (size_t)5 * readouts * d + (size_t)nk * 2 * d +
+                            (size_t)readouts * heads * nk + (size_t)readouts * hidden);
+}
+
+static int readout_check(const otter_readout_problem& q, int idx, ReadoutArgs& a) {
+    OTTER_REQUIRE(q.blocks && q.query && q.final_ln_w && q.final_ln_b && q.kv && q.out, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_readout_pool_fwd: problem %d has a null operand", idx);
+    OTTER_REQUIRE(q.n_blocks >= 1 && q.n_blocks <= MAX_BLOCKS, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: n_blocks=%d (1..%d)", q.n_blocks, MAX_BLOCKS);
+    OTTER_REQUIRE(q.n_obs > 0 && q.nk > 0 && q.nk <= 64 && q.readouts > 0 && q.readouts <= 16 && q.d > 0 && q.d <= 256 && q.heads > 0 &&
+                  q.d % q.heads == 0 && q.hidden > 0 && q.hidden <= 2048, OTTER_ERR_UNSUPPORTED_SHAPE,
+                  "otter_readout_pool_fwd: unsupported sizes n_obs=%d nk=%d R=%d d=%d heads=%d hidden=%d", q.n_obs, q.nk, q.readouts, q.d, q.heads, q.hidden);
+    OTTER_REQUIRE(q.ldkv >= (long)q.n_blocks * 2 * q.d && q.ldo >= (long)q.readouts * q.d, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_readout_pool_fwd: ldkv=%ld / ldo=%ld too small", q.ldkv, q.ldo);
+    a = ReadoutArgs{};
+    for (int b = 0; b < q.n_blocks; ++b) {
+        a.blk[b] = q.blocks[b];
+        const otter_readout_block& w = q.blocks[b];
+        OTTER_REQUIRE(w.q_ln_w && w.q_ln_b && w.wq_t && w.bq && w.wo_t && w.bo && w.ln_w && w.ln_b && w.fc1_t && w.fc1_b && w.fc2_t && w.fc2_b,
+                      OTTER_ERR_INVALID_ARGUMENT, "otter_readout_pool_fwd: block %d has a null parameter", b);
+    }
+    a.n_blocks = q.n_blocks; a.query = q.query; a.final_ln_w = q.final_ln_w; a.final_ln_b = q.final_ln_b;
+    a.kv = q.kv; a.ldkv = q.ldkv; a.mask = q.mask; a.out = q.out; a.ldo = q.ldo;
+    a.M = q.n_obs; a.nk = q.nk; a.R = q.readouts; a.d = q.d; a.heads = q.heads; a.hidden = q.hidden;
+    OTTER_REQUIRE(readout_lds_bytes(q.nk, q.readouts, q.d, q.heads, q.hidden) <= 160 * 1024, OTTER_ERR_UNSUPPORTED_SHAPE,
+                  "otter_readout_pool_fwd: needs %zu bytes of LDS (> 160 KiB)", readout_lds_bytes(q.nk, q.readouts, q.d, q.heads, q.hidden));
+    OTTER_REQUIRE((q.d * q.d) % 4 == 0 && (q.d * q.hidden) % 4 == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: d*d and d*hidden must be multiples of 4");
+    return OTTER_OK;
+}
+
+extern "C" int otter_readout_pool_fwd_multi(const otter_readout_problem* problems, int n_problems, void* stream) {
+    OTTER_REQUIRE(problems && n_problems >= 1 && n_problems <= MAX_PROBLEMS, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_readout_pool_fwd_multi: %d problems (1..%d)", n_problems, MAX_PROBLEMS);
+    ReadoutMulti mp{};
+    size_t lds = 0;
+    long total = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        if (problems[i].n_obs == 0) continue;                // an empty problem takes no workgroups
+        if (int rc = readout_check(problems[i], i, mp.a[mp.n])) return rc;
+        lds = std::max(lds, readout_lds_bytes(problems[i].nk, problems[i].readouts, problems[i].d, problems[i].heads, problems[i].hidden));
+        mp.first[mp.n] = (int)total;
+        total += problems[i].n_obs;
+        ++mp.n;
+    }
+    if (mp.n == 0) return OTTER_OK;
+    OTTER_REQUIRE(total < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd_multi: grid too large");
+    for (int i = mp.n; i <= MAX_PROBLEMS; ++i) mp.first[i] = (int)total;
+    if (int rc = otter_reserve_lds((const void*)readout_kernel, lds, "otter_readout_pool_fwd")) return rc;
+    hipLaunchKernelGGL(readout_kernel, dim3((unsigned)total), dim3(256), lds, (hipStream_t)stream, mp);
+    OTTER_CHECK_LAUNCH("otter_readout_pool_fwd");
+    return OTTER_OK;
+}
+
 extern "C" int otter_readout_pool_fwd(const otter_readout_block* blocks, int n_blocks, const float* query,
                                       const float* final_ln_w, const float* final_ln_b, const float* kv, long ldkv,
                                       const unsigned char* mask, float* out, long ldo, int n_obs, int nk, int readouts,
                                       int d, int heads, int hidden, void* stream) {
     OTTER_REQUIRE(blocks && query && final_ln_w && final_ln_b && kv && out, OTTER_ERR_INVALID_ARGUMENT, "otter_readout_pool_fwd: null operand");
     if (n_obs == 0) return OTTER_OK;
-    OTTER_REQUIRE(n_blocks >= 1 && n_blocks <= MAX_BLOCKS, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: n_blocks=%d (1..%d)", n_blocks, MAX_BLOCKS);
-    OTTER_REQUIRE(n_obs > 0 && nk > 0 && nk <= 64 && readouts > 0 && readouts <= 16 && d > 0 && d <= 256 && heads > 0 && d % heads == 0 &&
-                  hidden > 0 && hidden <= 2048, OTTER_ERR_UNSUPPORTED_SHAPE,
-                  "otter_readout_pool_fwd: unsupported sizes nk=%d R=%d d=%d heads=%d hidden=%d", nk, readouts, d, heads, hidden);
-    OTTER_REQUIRE(ldkv >= (long)n_blocks * 2 * d && ldo >= (long)readouts * d, OTTER_ERR_INVALID_ARGUMENT,
-                  "otter_readout_pool_fwd: ldkv=%ld / ldo=%ld too small", ldkv, ldo);
-    ReadoutArgs a{};
-    for (int b = 0; b < n_blocks; ++b) {
-        a.blk[b] = blocks[b];
-        const otter_readout_block& w = blocks[b];
-        OTTER_REQUIRE(w.q_ln_w && w.q_ln_b && w.wq_t && w.bq && w.wo_t && w.bo && w.ln_w && w.ln_b && w.fc1_t && w.fc1_b && w.fc2_t && w.fc2_b,
-                      OTTER_ERR_INVALID_ARGUMENT, "otter_readout_pool_fwd: block %d has a null parameter", b);
-    }
-    a.n_blocks = n_blocks; a.query = query; a.final_ln_w = final_ln_w; a.final_ln_b = final_ln_b;
-    a.kv = kv; a.ldkv = ldkv; a.mask = mask; a.out = out; a.ldo = ldo;
-    a.M = n_obs; a.nk = nk; a.R = readouts; a.d = d; a.heads = heads; a.hidden = hidden;
-    const size_t lds = sizeof(float) * ((size_t)2 * d * d + (size_t)d * hidden + (size_t)5 * readouts * d + (size_t)nk * 2 * d +
-                                       (size_t)readouts * heads * nk + (size_t)readouts * hidden);
-    OTTER_REQUIRE(lds <= 160 * 1024, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: needs %zu bytes of LDS (> 160 KiB)", lds);
-    OTTER_REQUIRE((d * d) % 4 == 0 && (d * hidden) % 4 == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_readout_pool_fwd: d*d and d*hidden must be multiples of 4");
-    if (int rc = otter_reserve_lds((const void*)readout_kernel, lds, "otter_readout_pool_fwd")) return rc;
-    hipLaunchKernelGGL(readout_kernel, dim3(n_obs), dim3(256), lds, (hipStream_t)stream, a);
-    OTTER_CHECK_LAUNCH("otter_readout_pool_fwd");
-    return OTTER_OK;
+    const otter_readout_problem q{blocks, n_blocks, query, final_ln_w, final_ln_b, kv, ldkv, mask, out, ldo, n_obs, nk, readouts, d, heads, hidden};
+    return otter_readout_pool_fwd_multi(&q, 1, stream);
 }

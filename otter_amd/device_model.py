@@ -318,16 +318,18 @@ class OtterDevice:
                 raise ValueError("pool_true_text models need a text mask")
             mask_b = text_mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mask_m = mask_b.repeat_interleave(t_rep, dim=0).contiguous() if t_rep > 1 else mask_b
+        # the poolings of all cameras and of the text (otter.py:247,254): projections first, then ONE readout launch
         off = self.d_text
+        problems = []
         for c in range(self.cams):
-            self.vis_pool[c].forward(ta[c].view(m * k, d), mask_m, combined[:, off:off + self.d_vis], m, k)
+            problems.append(self.vis_pool[c].problem(ta[c].view(m * k, d), mask_m, combined[:, off:off + self.d_vis], m, k))
             off += self.d_vis
         tfn = ops.l2norm_rows(text_feats.view(b * k, d))
-        if t_rep == 1:
-            self.text_pool.forward(tfn, mask_b, combined[:, : self.d_text], b, k)
-        else:
-            tt = torch.empty(b, self.d_text, dtype=torch.float32, device=self.device)
-            self.text_pool.forward(tfn, mask_b, tt, b, k)
+        tt = combined[:, : self.d_text] if t_rep == 1 else torch.empty(b, self.d_text, dtype=torch.float32, device=self.device)
+        problems.append(self.text_pool.problem(tfn, mask_b, tt, b, k))
+        for i in range(0, len(problems), 4):
+            ops.readout_pool_multi(problems[i:i + 4])
+        if t_rep != 1:
             ops.repeat_rows(tt, combined[:, : self.d_text], t_rep)
         h = ops.linear_f32(proprio, self.prop[0][0], self.prop[0][1], ops.ACT_RELU)
         h = ops.linear_f32(h, self.prop[1][0], self.prop[1][1], ops.ACT_RELU)

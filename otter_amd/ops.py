@@ -359,9 +359,9 @@ def text_aware_pool(patches: Tensor, text: Tensor, pos_packed: Tensor, temperatu
     return out
 
 
-def readout_pool(blocks, query: Tensor, final_w: Tensor, final_b: Tensor, kv: Tensor, mask: Optional[Tensor], out: Tensor,
-                 n_obs: int, nk: int, readouts: int, d: int, heads: int, hidden: int) -> Tensor:
-    """``blocks``: ctypes array of :class:`ReadoutBlock`; kv fp32 (n_obs*nk, >= n_blocks*2d); out fp32 view (n_obs, readouts*d)."""
+def _readout_check(query: Tensor, final_w: Tensor, final_b: Tensor, kv: Tensor, mask: Optional[Tensor], out: Tensor,
+                   n_obs: int, nk: int, readouts: int, d: int):
+    """Shape / type checks of one pooling; -> (ldkv, ldo)."""
     _chk(kv, torch.float32, "readout.kv", 2)
     rows, _, ldkv = _rows_view(kv, "readout.kv")
     if rows != n_obs * nk:
@@ -378,9 +378,30 @@ def readout_pool(blocks, query: Tensor, final_w: Tensor, final_b: Tensor, kv: Te
         _chk(t, torch.float32, "readout." + nme)
         if t.numel() != cnt or not t.is_contiguous():
             raise ValueError(f"readout.{nme}: bad size")
+    return ldkv, ldo
+
+
+def readout_pool(blocks, query: Tensor, final_w: Tensor, final_b: Tensor, kv: Tensor, mask: Optional[Tensor], out: Tensor,
+                 n_obs: int, nk: int, readouts: int, d: int, heads: int, hidden: int) -> Tensor:
+    """``blocks``: ctypes array of :class:`ReadoutBlock`; kv fp32 (n_obs*nk, >= n_blocks*2d); out fp32 view (n_obs, readouts*d)."""
+    ldkv, ldo = _readout_check(query, final_w, final_b, kv, mask, out, n_obs, nk, readouts, d)
     _lib.call("otter_readout_pool_fwd", blocks, len(blocks), _ptr(query), _ptr(final_w), _ptr(final_b), _ptr(kv), ldkv, _ptr(mask),
               _ptr(out), ldo, n_obs, nk, readouts, d, heads, hidden, _stream())
     return out
+
+
+def readout_pool_multi(problems) -> None:
+    """Several poolings in one launch.  ``problems``: sequence of tuples with the arguments of :func:`readout_pool`, in
+    its order (blocks, query, final_w, final_b, kv, mask, out, n_obs, nk, readouts, d, heads, hidden); at most 4."""
+    arr = (_lib.ReadoutProblem * len(problems))()
+    for q, (blocks, query, final_w, final_b, kv, mask, out, n_obs, nk, readouts, d, heads, hidden) in zip(arr, problems):
+        ldkv, ldo = _readout_check(query, final_w, final_b, kv, mask, out, n_obs, nk, readouts, d)
+        q.blocks, q.n_blocks = ctypes.cast(blocks, ctypes.POINTER(_lib.ReadoutBlock)), len(blocks)
+        q.query, q.final_ln_w, q.final_ln_b = query.data_ptr(), final_w.data_ptr(), final_b.data_ptr()
+        q.kv, q.ldkv, q.mask = kv.data_ptr(), ldkv, (None if mask is None else mask.data_ptr())
+        q.out, q.ldo = out.data_ptr(), ldo
+        q.n_obs, q.nk, q.readouts, q.d, q.heads, q.hidden = n_obs, nk, readouts, d, heads, hidden
+    _lib.call("otter_readout_pool_fwd_multi", arr, len(problems), _stream())
 
 
 def l2norm_rows(x: Tensor) -> Tensor:

@@ -62,12 +62,16 @@ class PoolingWeights:
         self.kv_b = torch.cat(bs, 0).contiguous()
         self.blocks = blocks
 
-    def forward(self, x: Tensor, mask: Optional[Tensor], out: Tensor, n_obs: int, nk: int) -> Tensor:
-        """x fp32 (n_obs*nk, D_in); mask bool/uint8 (n_obs, nk) with True = ignore; out fp32 view (n_obs, readouts*d)."""
+    def problem(self, x: Tensor, mask: Optional[Tensor], out: Tensor, n_obs: int, nk: int):
+        """Key / value projection of ``x`` (launched here) and the argument tuple of the readout that consumes it, for
+        :func:`ops.readout_pool` or, with the other poolings of the same encoder call, :func:`ops.readout_pool_multi`."""
         xn = ops.layernorm(x, None, None, out_dtype=torch.float32)
         kv = ops.gemm(xn, self.kv_w, self.kv_n, self.kv_b, out_f32=True)
         m8 = None
         if mask is not None:
             m8 = mask.to(torch.uint8).contiguous()
-        return ops.readout_pool(self.blocks, self.query, self.final_w, self.final_b, kv, m8, out, n_obs, nk,
-                                self.readouts, self.d, self.heads, self.hidden)
+        return (self.blocks, self.query, self.final_w, self.final_b, kv, m8, out, n_obs, nk, self.readouts, self.d, self.heads, self.hidden)
+
+    def forward(self, x: Tensor, mask: Optional[Tensor], out: Tensor, n_obs: int, nk: int) -> Tensor:
+        """x fp32 (n_obs*nk, D_in); mask bool/uint8 (n_obs, nk) with True = ignore; out fp32 view (n_obs, readouts*d)."""
+        return ops.readout_pool(*self.problem(x, mask, out, n_obs, nk))

@@ -433,6 +433,40 @@ def test_readout_pool(dev, case_name):
     assert torch.all(out[:, :4] == 0) and torch.all(out[:, 4 + case["D_out"]:] == 0)
 
 
+def test_readout_pool_multi_matches_single_launches(dev):
+    """Three poolings of different widths, key counts and batch sizes in one launch: the same bits as one launch each
+    (a workgroup does not know what else is in the grid), an empty problem skipped, a fifth problem refused."""
+    import golden_inputs as GI
+    from otter_amd import ops
+    from otter_amd.params import pooling_specs, random_state_dict
+    from otter_amd.pooling import PoolingWeights
+    single, multi, problems = [], [], []
+    keep = []
+    for case in (c for name in ("vision_nomask", "text_mask", "small") for c in GI.POOL_CASES if c["name"] == name):
+        sd = random_state_dict(pooling_specs("", case["D_in"], case["D_out"], case["layers"], case["readouts"]), seed=case["seed"])
+        x, mask = GI.pool_inputs(case)
+        pw = PoolingWeights({k: v.to(dev) for k, v in sd.items()}, "", case["heads"])
+        keep.append(pw)
+        xd, md = x.to(dev).reshape(-1, case["D_in"]), None if mask is None else mask.to(dev)
+        single.append(pw.forward(xd, md, torch.zeros(case["B"], case["D_out"], device=dev), case["B"], case["K"]))
+        multi.append(torch.zeros(case["B"], case["D_out"], device=dev))
+        problems.append(pw.problem(xd, md, multi[-1], case["B"], case["K"]))
+    assert len({(p[7], p[8], p[10]) for p in problems}) == len(problems) == 3          # different (n_obs, nk, d)
+    ops.readout_pool_multi(problems)
+    for a, b in zip(single, multi):
+        assert torch.equal(a, b)
+    empty = list(problems[1])
+    empty[4], empty[6], empty[7] = empty[4][:0], empty[6][:0], 0
+    if empty[5] is not None:
+        empty[5] = empty[5][:0]
+    for m in multi:
+        m.zero_()
+    ops.readout_pool_multi([problems[0], tuple(empty), problems[2]])
+    assert torch.equal(multi[0], single[0]) and torch.equal(multi[2], single[2]) and torch.all(multi[1] == 0)
+    with pytest.raises(ops.OtterHipError):
+        ops.readout_pool_multi([problems[0]] * 5)
+
+
 def test_small_ops(dev):
     from otter_amd import ops
     x = _randn(26, 33, 768).to(dev)

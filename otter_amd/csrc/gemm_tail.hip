@@ -2,12 +2,14 @@
 //   * the < 256 remainder rows of a big 16-bit GEMM whose whole 256-row tiles run in the 256x256 kernel (running
 //     them beside the big kernel on a second stream was measured and lost to the cross-stream fork/join cost);
 //   * any GEMM too small to give the 128x128 kernel one tile per CU (policy transformer, pooling projections, heads).
-// Such problems are latency-bound: small tiles spread them over 4x more CUs and four LDS stages keep three
-// K-steps of loads in flight per workgroup.
+// Such problems are latency-bound: small tiles spread them over 4x more CUs and five LDS stages (two workgroups per
+// CU) keep three K-steps of loads in flight per workgroup behind the one whose fragments are being read.
 //
 // Layout as in gemm.hip: LDS-DMA staging with the chunk swizzle on the source address, weight rows as the MFMA
 // "A" operand; the weight rows of a wave's 32 columns are permuted so that a lane's two n-tiles hold 8
 // consecutive output columns (16-byte stores), as in gemm256.hip.
+#include <type_traits>
+
 #include "common.hpp"
 #include "otter_hip.h"
 
@@ -62,7 +64,13 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
     const int g = lane >> 4, li = lane & 15;
-    const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+    // Workgroup b runs on XCD b % 8, each with an L2 of its own: XCD x takes a contiguous run of the tile order (row tiles
+    // fastest), i.e. all row tiles of a few column panels, so a weight panel is fetched into one L2 instead of all eight
+    // (with the plain order every XCD pulled every panel of both operands through the fabric: 8 x 12.6 MB for 514 x 1024 x
+    // 4096, which set the time of such launches).
+    const int nt = p.tiles_m * p.tiles_n, xcd = blockIdx.x & 7;
+    const int tile = xcd * (nt >> 3) + min(xcd, nt & 7) + (int)(blockIdx.x >> 3);
+    const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
     const int m0 = tm * TB, n0 = tn * TB;
 
     // staging: a stage is 128 image rows (64 of A, then 64 of W) = 16 instructions of 8 rows; wave w issues 4w..4w+3
@@ -104,28 +112,61 @@ __global__ __launch_bounds__(256) void gemm_64x64(TailArgs p) {
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) stage(t, kbase + (unsigned)t * ROWB);
-    for (int t = 0; t < nk; ++t) {
-        // stages t .. t+NS-2 have been issued (4 instructions each per thread): retire stage t only
-        if (t + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");           // stage t visible to all waves; everyone is done with stage t-1
-        if (t + NS - 1 < nk) stage((t + NS - 1) % NS, kbase + (unsigned)(t + NS - 1) * ROWB);
+
+    // The K loop is a chain per wave -- wait for a stage, barrier, fragment reads (LDS latency), 8 MFMAs, 4 LDS-DMA
+    // requests (which hold the wave while the CU's address unit works through the four waves' 16 KiB) -- and the four waves
+    // run it in lock-step, so nothing of it overlaps unless it is made to: the fragments of stage t+1 are read one
+    // iteration ahead into a second register set (their latency passes under the MFMAs of stage t), and the requests of
+    // stage t+NS-1 follow the MFMAs (which run in the matrix pipe meanwhile).  Stage t+NS-1 overwrites the buffer of stage
+    // t-1, whose fragments every wave had in registers before it issued MFMAs(t-1), i.e. before it reached barrier t.
+    frag_t wf[2][2][2], af[2][2][2];                    // [register set][k-half][tile]
+    auto read_frags = [&](auto set_tag, int t) {
+        constexpr int S = decltype(set_tag)::value;
         const int cur = t % NS;
         const char* sA = smem + cur * STAGE + wm * 32 * ROWB;
         const char* sW = smem + cur * STAGE + TB * ROWB + wn * 32 * ROWB;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int off = row_off + (((ks * 4 + g) ^ swz) << 4);
-            frag_t wf[2], af[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) wf[j] = *(const frag_t*)(sW + j * 16 * ROWB + off);
+            for (int j = 0; j < 2; ++j) wf[S][ks][j] = *(const frag_t*)(sW + j * 16 * ROWB + off);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *(const frag_t*)(sA + i * 16 * ROWB + off);
+            for (int i = 0; i < 2; ++i) af[S][ks][i] = *(const frag_t*)(sA + i * 16 * ROWB + off);
+        }
+    };
+    // stage 0: min(nk, NS-1) stages are in flight
+    if (NS - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    read_frags(std::integral_constant<int, 0>{}, 0);
+    auto k_step = [&](auto set_tag, int t) {
+        constexpr int S = decltype(set_tag)::value;
+        if (t + 1 < nk) {
+            // stages t+1 .. min(nk-1, t+NS-2) are in flight: retire stage t+1 only
+            if (t + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 3)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");       // stage t+1 visible to all waves; everyone holds stage t in registers
+        }
+        // MFMAs first: the wait for their fragments (requested an iteration ago) must not cover the reads issued below
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mma_t<T>(wf[j], af[i], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma_t<T>(wf[S][ks][j], af[S][ks][i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nk) read_frags(std::integral_constant<int, S ^ 1>{}, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + NS - 1 < nk) stage((t + NS - 1) % NS, kbase + (unsigned)(t + NS - 1) * ROWB);
+    };
+    {
+        int t = 0;
+        for (; t + 1 < nk; t += 2) {
+            k_step(std::integral_constant<int, 0>{}, t);
+            k_step(std::integral_constant<int, 1>{}, t + 1);
         }
+        if (t < nk) k_step(std::integral_constant<int, 0>{}, t);
     }
 
     // epilogue: lane holds row m = li (per m-tile) and columns 8g + 0..7 of the wave's 32
@@ -212,7 +253,7 @@ template <typename T, int ACT, bool OUT_F32, bool RES>
 int launch_tail(const TailArgs& a, hipStream_t s) {
     // (8 stages for launches with fewer tiles than CUs were measured: no change -- such launches are bound by the 16 KiB
     //  per K-step that one CU can pull through its L1, not by the pipeline depth)
-    return launch_tail_ns<T, ACT, OUT_F32, RES, 4>(a, s);
+    return launch_tail_ns<T, ACT, OUT_F32, RES, 5>(a, s);
 }
 
 template <int ACT>
@@ -326,9 +367,9 @@ int otter_gemm64_splitk_launch(int dtype, const void* A, long lda, const void* W
                                const float* ln_colsum, float* workspace, int splits, hipStream_t s) {
     TailArgs a{(const char*)A, lda, (const char*)W, nullptr, nullptr, 0, nullptr, 0, M, N, K, (M + TB - 1) / TB, (N + TB - 1) / TB,
                nullptr, nullptr, splits, workspace};
-    int rc = dtype == DT_BF16 ? launch_tail_ns<__bf16, ACT_NONE, true, false, 4>(a, s)
-             : dtype == DT_F16 ? launch_tail_ns<_Float16, ACT_NONE, true, false, 4>(a, s)
-                               : launch_tail_ns<float, ACT_NONE, true, false, 4>(a, s);
+    int rc = dtype == DT_BF16 ? launch_tail_ns<__bf16, ACT_NONE, true, false, 5>(a, s)
+             : dtype == DT_F16 ? launch_tail_ns<_Float16, ACT_NONE, true, false, 5>(a, s)
+                               : launch_tail_ns<float, ACT_NONE, true, false, 5>(a, s);
     if (rc != OTTER_OK) return rc;
     ReduceArgs r{workspace, splits, bias, residual, ldr, C, ldc, M, N, act, out_f32 ? DT_F32 : dtype, res ? 1 : 0, ln_stats, ln_colsum};
     const long threads = (long)M * (N / 4);

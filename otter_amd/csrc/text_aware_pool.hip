@@ -26,6 +26,9 @@
 #include "common.hpp"
 #include "otter_hip.h"
 
+#ifndef TAVE_TILE_CPOL
+#define TAVE_TILE_CPOL 2      // patch tiles are read once: nt (streaming) policy, +2 % at chip-filling sizes
+#endif
 namespace {
 
 struct TaveArgs {
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
         char* dst = sX + buf * TILE_B;
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + min(src_off[i], lim)), LDS_PTR(dst + (wave * NLD + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + min(src_off[i], lim)), LDS_PTR(dst + (wave * NLD + i) * 1024), 16, 0, TAVE_TILE_CPOL);
     };
     stage(0, 0);
     if (PF > 1 && nt > 1) stage(1, 1);

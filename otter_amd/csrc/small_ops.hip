@@ -31,6 +31,42 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* images, T* out,
     }
 }
 
+// uint8 frames, one workgroup per (image, row of patches): the 3 x ps x res bytes of the band are copied to LDS with coalesced
+// 4-byte loads (a patch row is only ps bytes long: read from memory one output element at a time, the kernel above ran at
+// 1 TB/s), then every thread builds 8 consecutive output columns at a time (16-byte stores).  The index split k -> (c, ky, kx)
+// is done once per 8 columns.  Same arithmetic per element as above (bit-identical results).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_u8_band(const unsigned char* images, T* out, int res, int ps, int g, int kpad,
+                                                     float m0, float m1, float m2, float s0, float s1, float s2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char band[];      // [3][ps][res]
+    typedef typename Half16<T>::v8 v8;
+    const int img = blockIdx.x / g, py = blockIdx.x % g;
+    const int rowb = ps * res, pp = ps * ps, kk = 3 * pp;
+    for (int c = 0; c < 3; ++c) {
+        const unsigned char* src = images + ((long)(img * 3 + c) * res + (long)py * ps) * res;
+        for (int i = threadIdx.x * 4; i < rowb; i += 1024) *(unsigned*)(band + c * rowb + i) = *(const unsigned*)(src + i);
+    }
+    __syncthreads();
+    const int cpr = kpad >> 3;                          // 8-column chunks per output row
+    for (int ch = threadIdx.x; ch < g * cpr; ch += 256) {
+        const int px = ch / cpr, k0 = (ch - px * cpr) * 8;
+        int c = k0 / pp, rem = k0 - c * pp;
+        int ky = rem / ps, kx = rem - ky * ps;
+        v8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = 0.f;
+            if (k0 + e < kk) {
+                const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), std = c == 0 ? s0 : (c == 1 ? s1 : s2);
+                v = ((float)band[c * rowb + ky * res + px * ps + kx] / 255.0f - mean) / std;
+            }
+            o[e] = Half16<T>::from(v);
+            if (++kx == ps) { kx = 0; if (++ky == ps) { ky = 0; ++c; } }
+        }
+        *(v8*)(out + ((long)(img * g + py) * g + px) * kpad + k0) = o;
+    }
+}
+
 // ---------------------------------------------------------------- y = x / ||x||_2 per row (fp32 in/out)
 template <typename T>
 __global__ __launch_bounds__(256) void l2norm_kernel(const T* x, long ldx, float* y, long ldy, int rows, int width) {
@@ -141,7 +177,11 @@ __global__ __launch_bounds__(256) void window_append_kernel(const float* src, co
 template <typename T>
 static void launch_im2col(const void* images, int is_u8, void* out, int n_img, int res, int patch, int g, int kpad,
                           const float* mean3, const float* std3, hipStream_t s) {
-    if (is_u8)
+    const int band_bytes = 3 * patch * res;
+    if (is_u8 && res % 4 == 0 && band_bytes <= 64 * 1024 && ((uintptr_t)images & 3) == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL((im2col_u8_band<T>), dim3(n_img * g), dim3(256), band_bytes, s, (const unsigned char*)images, (T*)out, res, patch, g,
+                           kpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    else if (is_u8)
         hipLaunchKernelGGL((im2col_kernel<true, T>), dim3(n_img * g * g), dim3(256), 0, s, images, (T*)out, res, patch, g, kpad,
                            mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     else

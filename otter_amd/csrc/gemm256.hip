@@ -45,7 +45,11 @@ constexpr int TM = 256, TN = 256;
 constexpr int HALF_BYTES = 128 * 128;             // one half-tile
 constexpr int STAGE_BYTES = 2048;                 // per wave: epilogue operands staged through LDS (see stage_fetch)
 constexpr int LDS_BYTES = 2 * 4 * HALF_BYTES + 8 * STAGE_BYTES;     // 128 KiB of tiles + 16 KiB
-constexpr int GROUP_M256 = 8;     // tile order: groups of 8 row tiles swept along N (measured against 2, 4, 16, 32 on the ViT-L shapes)
+// Tile order: groups of `group_m` row tiles swept along N (Gemm256Args::group_m, chosen per shape on the host).  Measured in the
+// step, where the operands of a launch come from memory (a loop over one launch keeps them in the caches and shows no
+// difference): 8 for outputs of up to 12 column tiles (against 2, 4, 6, 16, 32 on the ViT-L shapes), 6 for 16 column tiles
+// (fc1, N = 4096: step -0.6 % against 8; 4 and 5 -0.45 %, 7 -0.3 %).
+constexpr int GROUP_M256 = 8, GROUP_M256_WIDE = 6;
 
 struct Gemm256Args {
     const char* A; long lda;
@@ -54,6 +58,7 @@ struct Gemm256Args {
     const void* residual; long ldr;     // in the OUTPUT's type: fp32 with OUT_F32, else the 16-bit operand type
     void* C; long ldc;
     int M, N, K, tiles_m, tiles_n;
+    int group_m;                // row tiles per group of the tile order
     const float* ln_stats;      // [M][2] (mean, rstd) or null: LayerNorm folded into the epilogue (see otter_gemm_ln)
     const float* ln_colsum;     // [N]
 };
@@ -108,9 +113,9 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     // Tile `t` of the launch order -> (m0, n0); scalar arithmetic
     auto tile_origin = [&](int t, int& m0, int& n0) {
         const int pid = xcd_remap(t, nwg);
-        const int width = GROUP_M256 * p.tiles_n;
-        const int first_m = (pid / width) * GROUP_M256;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M256);
+        const int width = p.group_m * p.tiles_n;
+        const int first_m = (pid / width) * p.group_m;
+        const int gsz = min(p.tiles_m - first_m, p.group_m);
         m0 = (first_m + (pid % width) % gsz) * TM;
         n0 = ((pid % width) / gsz) * TN;
     };
@@ -458,6 +463,8 @@ int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, cons
         otter_set_error("otter_gemm (256x256): M=%d is not a positive multiple of %d", M, TM);
         return OTTER_ERR_UNSUPPORTED_SHAPE;
     }
-    Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, (N + TN - 1) / TN, ln_stats, ln_colsum};
+    const int tiles_n = (N + TN - 1) / TN;
+    const int group_m = tiles_n >= 16 ? GROUP_M256_WIDE : GROUP_M256;
+    Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, tiles_n, group_m, ln_stats, ln_colsum};
     return dtype == DT_BF16 ? dispatch256<__bf16>(a, act, out_f32, res, s) : dispatch256<_Float16>(a, act, out_f32, res, s);
 }

@@ -49,6 +49,10 @@ constexpr int LDS_BYTES = 2 * 4 * HALF_BYTES + 8 * STAGE_BYTES;     // 128 KiB o
 // step, where the operands of a launch come from memory (a loop over one launch keeps them in the caches and shows no
 // difference): 8 for outputs of up to 12 column tiles (against 2, 4, 6, 16, 32 on the ViT-L shapes), 6 for 16 column tiles
 // (fc1, N = 4096: step -0.6 % against 8; 4 and 5 -0.45 %, 7 -0.3 %).
+// Outputs of at most four column tiles (out_proj, fc2) take the tile order as it is instead of one contiguous chunk per XCD:
+// workgroups go to the XCDs round-robin, so with groups of 8 row tiles XCD x gets row tile x of every group with all its
+// column tiles -- one A panel and the whole (narrow) weight in its L2 (step -0.45 % in four same-box rounds, all of it from
+// out_proj; for the wide outputs the chunked map wins by 0.4-0.9 % of the step per shape).
 constexpr int GROUP_M256 = 8, GROUP_M256_WIDE = 6;
 
 struct Gemm256Args {
@@ -59,6 +63,7 @@ struct Gemm256Args {
     void* C; long ldc;
     int M, N, K, tiles_m, tiles_n;
     int group_m;                // row tiles per group of the tile order
+    int xcd_chunks;             // 1: each XCD works on one contiguous chunk of the tile order; 0: workgroup b starts at tile b
     const float* ln_stats;      // [M][2] (mean, rstd) or null: LayerNorm folded into the epilogue (see otter_gemm_ln)
     const float* ln_colsum;     // [N]
 };
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void gemm_256x256(Gemm256Args p) {
     }
     // Tile `t` of the launch order -> (m0, n0); scalar arithmetic
     auto tile_origin = [&](int t, int& m0, int& n0) {
-        const int pid = xcd_remap(t, nwg);
+        const int pid = p.xcd_chunks ? xcd_remap(t, nwg) : t;
         const int width = p.group_m * p.tiles_n;
         const int first_m = (pid / width) * p.group_m;
         const int gsz = min(p.tiles_m - first_m, p.group_m);
@@ -465,6 +470,7 @@ int otter_gemm256_launch(int dtype, const void* A, long lda, const void* W, cons
     }
     const int tiles_n = (N + TN - 1) / TN;
     const int group_m = tiles_n >= 16 ? GROUP_M256_WIDE : GROUP_M256;
-    Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, tiles_n, group_m, ln_stats, ln_colsum};
+    const int xcd_chunks = tiles_n <= 4 ? 0 : 1;
+    Gemm256Args a{(const char*)A, lda, (const char*)W, bias, residual, ldr, C, ldc, M, N, K, (M + TM - 1) / TM, tiles_n, group_m, xcd_chunks, ln_stats, ln_colsum};
     return dtype == DT_BF16 ? dispatch256<__bf16>(a, act, out_f32, res, s) : dispatch256<_Float16>(a, act, out_f32, res, s);
 }

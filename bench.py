@@ -65,13 +65,15 @@ def pmc_counters_of_this_kernel():
         return None, None, None, f"unreadable counter file: {exc}"
 
 
-def build_model(device, seed=0, clip_dtype=torch.float16):
+def build_model(device, seed=0, clip_dtype=torch.float16, sd=None):
+    """Default-config OTTER with random-init weights (``sd``: reuse another instance's checkpoint instead of drawing one)."""
     from otter_amd.config import ModelConfig, SharedConfig
     from otter_amd.otter import OTTER
     from otter_amd.params import otter_specs, random_state_dict
     mc, sc = ModelConfig(), SharedConfig()
     model = OTTER(mc, sc)
-    sd = random_state_dict(otter_specs(mc, sc), seed=seed)
+    if sd is None:
+        sd = random_state_dict(otter_specs(mc, sc), seed=seed)
     model.load_state_dict(sd, strict=True)
     model.clip_compute_dtype = clip_dtype
     return model.to(device).eval(), sd, mc, sc
@@ -90,9 +92,9 @@ def synthetic_tokens(n, rng):
 
 
 class Workload:
-    def __init__(self, device, seed, clip_dtype=torch.float16):
+    def __init__(self, device, seed, clip_dtype=torch.float16, sd=None):
         from otter_amd.engine import BatchedRollout
-        self.model, self.sd, self.mc, self.sc = build_model(device, clip_dtype=clip_dtype)
+        self.model, self.sd, self.mc, self.sc = build_model(device, clip_dtype=clip_dtype, sd=sd)
         self.dev = self.model.device_model()
         self.n = PER_GPU_EPISODES
         rng = np.random.default_rng(seed)
@@ -186,9 +188,9 @@ class TrainWorkload:
     parameters + gradient all-reduce + AdamW."""
     PER_GPU_WINDOWS = 16
 
-    def __init__(self, device, seed, clip_dtype=torch.float16):
+    def __init__(self, device, seed, clip_dtype=torch.float16, sd=None):
         from otter_amd.trainer import Trainer
-        self.model, self.sd, self.mc, self.sc = build_model(device, clip_dtype=clip_dtype)
+        self.model, self.sd, self.mc, self.sc = build_model(device, clip_dtype=clip_dtype, sd=sd)
         self.model.train()
         self.trainer = Trainer(self.model, lr=3e-4, weight_decay=0.01, warmup_steps=10, num_steps=1000)
         self.dev = None
@@ -344,6 +346,148 @@ def cpu_baseline(work: Workload, budget_s: float = 15.0):
                 sample=f"{n} single-episode observations (2 cams 224^2, default config, fp32 torch-CPU oracle, {el:.1f} s)")
 
 
+# ------------------------------------------------------------------------------- the other configurations, one block each
+IMAGE_GFLOP = 158.11         # tower work one 224^2 image needs (patch embed + 23 blocks + last attention + patch projection)
+TEXT_GFLOP_15 = 2.57         # text tower over the first 15 positions of one prompt
+
+
+def _timed(fn, steps: int) -> float:
+    """Seconds for `steps` calls of fn, device drained on both sides."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def _step_roofline(tflop_per_step: float, seconds_per_step: float) -> dict:
+    """Whole-step MFMA roofline: the towers' algorithmic FLOPs of one step over the step's wall time (everything else in
+    the step -- attention softmax, pooling, policy, launch gaps -- counts as time and not as work)."""
+    tf = tflop_per_step / seconds_per_step
+    return {"bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS,
+            "work": "algorithmic tower FLOPs of the step / wall time of the step"}
+
+
+def bf16_point(device, base: "Workload", steps: int = 12, warmup: int = 3) -> dict:
+    """The same workload with bf16 MFMA operands in the towers (what the configuration names; the headline runs fp16
+    operands because bf16 misses the 1e-3 action tolerance).  Also the largest action difference between the two operand
+    types on one identical first step of an episode."""
+    w = Workload(device, seed=0, clip_dtype=torch.bfloat16, sd=base.sd)
+    w.images, w.proprio, w.tokens = base.images, base.proprio, base.tokens
+    for _ in range(warmup):
+        w.step()
+    w.t = 0
+    el = _timed(w.step, steps)
+    base.t = w.t = 0
+    diff = float((base.step().float() - w.step().float()).abs().max())
+    base.t = 0
+    out = {"value": w.n * steps / el, "unit": "obs/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "dtype": "bf16",
+           "roofline": _step_roofline(2 * w.n * IMAGE_GFLOP / 1e3, el / steps), "max_abs_action_diff_vs_f16_operands": diff,
+           "note": "bf16 tower operands with the fp32 residual stream; parity tests hold this configuration to 2e-3, not 1e-3"}
+    del w
+    return out
+
+
+def config3_train(device, base: "Workload", clip_dtype, steps: int = 3, warmup: int = 2) -> dict:
+    """One data-parallel rank of the global-batch-128 training step (16 windows x 12 observations = 384 images)."""
+    w = TrainWorkload(device, seed=0, clip_dtype=clip_dtype, sd=base.sd)
+    for _ in range(warmup):
+        w.step()
+    el = _timed(w.step, steps)
+    out = {"value": w.n * steps / el, "unit": "obs/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "per_gpu_batch": w.n,
+           "roofline": _step_roofline(2 * w.n * IMAGE_GFLOP / 1e3, el / steps), "last": w.last,
+           "workload": "training step: frozen 16-bit MFMA towers, fp32 hand-written backward of the 31M trainable parameters, flat-buffer "
+                       "gradient all-reduce (a no-op on one rank), AdamW; 16 windows x 12 two-camera observations per GPU"}
+    del w
+    return out
+
+
+def config4_openclip_extract(device, clip_dtype, pairs: int = 256, steps: int = 5, warmup: int = 2) -> dict:
+    """OpenCLIP ViT-L/14 (GELU) text-aware feature extraction on `pairs` (image, prompt) pairs per step: both towers, the
+    pooled text feature as a 16th query, temperature 0.005 (script/open_clip_visualization.py:38-117)."""
+    from otter_amd import ops
+    from otter_amd.config import clip_arch
+    from otter_amd.device_model import ClipDevice
+    from otter_amd.params import clip_specs, random_state_dict, sincos_position_embedding
+    arch = clip_arch("open_clip:ViT-L-14")
+    sd = random_state_dict(clip_specs(arch), seed=3)
+    clip = ClipDevice(sd, arch, 15, device, clip_dtype)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    images = torch.randint(0, 256, (pairs, 3, 224, 224), dtype=torch.uint8, generator=g).to(device)
+    ids = synthetic_tokens(pairs, np.random.default_rng(4)).to(device)
+    pos_t = ops.pos_emb_pack(sincos_position_embedding(256, arch.embed_dim).to(device), clip_dtype)[None].contiguous()
+    temp = torch.full((1,), 0.005, device=device)
+
+    def step():
+        tokens, p, _ = clip.vision_tokens(images)
+        tf = clip.text_tokens(ids, pooled_row=True)                       # (pairs, 16, D): no prompt cache, as the script runs it
+        return ops.text_aware_pool(tokens, tf, pos_t, temp, pairs, 1, 1, n_patches=p)
+
+    for _ in range(warmup):
+        step()
+    el = _timed(step, steps)
+    return {"value": pairs * steps / el, "unit": "pairs/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "pairs_per_step": pairs,
+            "roofline": _step_roofline(pairs * (IMAGE_GFLOP + TEXT_GFLOP_15) / 1e3, el / steps),
+            "workload": "OpenCLIP ViT-L/14 (GELU-erf MLP) image + text towers and the fused text-aware pooling with 16 queries, "
+                        "random-init weights, prompts tokenised ahead"}
+
+
+def config5_long_history(device, base: "Workload", window: int = 32, warmup: int = 2) -> dict:
+    """64 concurrent episodes (one GPU's share of 512) with a history window of 32: `window` steps filling the per-layer
+    K/V cache, then `window` steps with the window sliding (whole-window recompute: 2048 rows through the policy)."""
+    from otter_amd.device_model import OtterDevice
+    from otter_amd.engine import BatchedRollout
+    from otter_amd.params import sinusoidal_table
+    m = base.model
+    sd = dict(base.sd)
+    sd["pe.pe"] = sinusoidal_table(window, base.mc.transformer_dim)
+    dev5 = OtterDevice(sd, m.clip_arch, first_k=m.first_k_tokens, pooling_heads=m.pooling_heads, transformer_heads=m.transformer_heads,
+                       num_cameras=len(m.camera_keys), seq_length=window, action_horizon=m.action_horizon, action_dim=m.action_dim,
+                       pool_true_text=m.pool_true_text, device=device, clip_dtype=m.clip_compute_dtype, clip=base.dev.clip)
+    ro = BatchedRollout(dev5, base.n)
+    text = base.dev.clip.text_tokens_cached(base.tokens)
+    t = [0]
+
+    def step():
+        i = t[0] % base.n_sets
+        t[0] += 1
+        return ro.step(base.images[i], text, base.proprio[i])
+
+    for _ in range(warmup):
+        step()
+    ro.reset()
+    fill = _timed(step, window)
+    slide = _timed(step, window)
+    el, steps = fill + slide, 2 * window
+    return {"value": base.n * steps / el, "unit": "obs/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+            "ms_per_step_fill": 1e3 * fill / window, "ms_per_step_slide": 1e3 * slide / window, "per_gpu_episodes": base.n, "history": window,
+            "roofline": _step_roofline(2 * base.n * IMAGE_GFLOP / 1e3, el / steps),
+            "workload": f"{base.n} episodes per GPU, history window {window}: {window} cached-K/V fill steps + {window} sliding steps"}
+
+
+def self_launch(args) -> int:
+    """`bench.py --gpus N` started bare (no torchrun around it): this parent, which has made no GPU call, starts the N
+    ranks as a child `python -m torch.distributed.run ...` of the same command and relays rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    for ln in res.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    return res.returncode if res.returncode != 0 or lines else 1
+
+
 def timed_composition(steps: int) -> str:
     fill = sum(1 for t in range(steps) if t % EPISODE_LEN < 12)
     return f"{fill} fill + {steps - fill} slide steps"
@@ -360,6 +504,8 @@ def main():
                     help="infer: batched rollout (the headline metric); train: one data-parallel training step per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the side blocks of the N=1 line (bf16 operands, training step, OpenCLIP extraction, history 32)")
     ap.add_argument("--no-reference-points", action="store_true",
                     help="skip the two side measurements (vendor-library GEMM rate, pooling kernel at a chip-filling size): profiles of "
                          "the step then hold the step's kernels only")
@@ -368,6 +514,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))              # started bare: become the launcher of N ranks
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     # One process per GPU.  OTTER_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks
@@ -458,6 +606,18 @@ def main():
             result["value_incl_h2d"] = {"value": work.n * args.steps / el, "unit": "obs/s", "ms_per_step": 1e3 * el / args.steps,
                                         "note": "same steps with the uint8 frames (19.3 MB per step) and proprioception uploaded from pinned host "
                                                 "memory every step on a copy stream, one step ahead, after 12 untimed steps through the same pipeline; never the headline value"}
+        if world == 1 and args.workload == "infer" and not stub and not args.no_other_configs:
+            # the other configurations, each a block of its own (never the headline value); a failure in one is reported
+            # in its block and does not take the line down
+            for name, fn in (("value_bf16", lambda: bf16_point(device, work)),
+                             ("config5_long_history", lambda: config5_long_history(device, work)),
+                             ("config4_openclip_extract", lambda: config4_openclip_extract(device, clip_dtype)),
+                             ("config3_train", lambda: config3_train(device, work, clip_dtype))):
+                try:
+                    result[name] = fn()
+                except Exception as exc:                     # noqa: BLE001
+                    result[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and args.workload == "infer":
             result["cpu_baseline"] = cpu_baseline(work)
         print(json.dumps(result))

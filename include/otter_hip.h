@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 12
+#define OTTER_HIP_ABI_VERSION 13
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -75,8 +75,14 @@ int otter_gemm_ws(int dtype, const void* A, long lda, const void* W, int n_pad, 
  * held until the process ends), so no workspace is passed and the call allocates nothing.  No counterpart in the
  * reference.  N <= otter_gemm_static_ws_max_n() (4096), larger N is rejected with OTTER_ERR_UNSUPPORTED_SHAPE; results
  * are bit-identical to otter_gemm_ws with a workspace of otter_gemm_workspace_floats(N) floats.  Every call on one GPU
- * shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race; serialise them. */
+ * shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race; serialise them.
+ * Set-up: the array's device address is looked up once per GPU (hipGetSymbolAddress, which may load the code object and
+ * is therefore neither allocation-free nor legal under stream capture).  otter_gemm_static_ws_init() does that look-up for
+ * the CURRENT device; call it once per GPU before the first capture.  Without it the first otter_gemm_static_ws call on a
+ * GPU does the look-up itself -- and refuses (OTTER_ERR_LAUNCH) if its stream is being captured at that moment.  The
+ * stream must belong to the current device (checked). */
 long otter_gemm_static_ws_max_n(void);
+int otter_gemm_static_ws_init(void);
 int otter_gemm_static_ws(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const void* residual,
                          long ldr, const float* row_stats, const float* col_sum, void* C, long ldc, int M, int N, int K,
                          int epilogue, void* stream);
@@ -123,6 +129,15 @@ int otter_attn_fwd_d64(int dtype, const void* qkv, long ld, void* out, long ldo,
  * 0 .. its own position.  out: fp32 rows (b*n_query + i), width heads*head_dim.  window <= 64. */
 int otter_attn_policy(const float* qkv, long ld, float* out, long ldo, int batch, int window, int n_query, int pos0,
                       int heads, int head_dim, void* stream);
+
+/* The same attention for episodes that are at DIFFERENT positions of their windows (a server whose episodes start and
+ * end independently; per-episode semantics of otter.py:153-175,319-329).  Row i is the newest step of episode idx[i], at
+ * window position lens[idx[i]] - 1 (lens: per-episode lengths after this step's append, device int32).  fresh: fp32
+ * [n_rows][ldf] q|k|v rows of the new steps; each is stored into its episode's row of `cache`
+ * ([n_episodes][window][ld], the K/V history) and attends over that episode's earlier rows plus itself.
+ * out: fp32 [n_rows][ldo].  window <= 64; idx values outside [0, n_episodes) and lengths outside [1, window] are clamped. */
+int otter_attn_policy_rows(const float* fresh, long ldf, float* cache, long ld, float* out, long ldo, const int* idx,
+                           const int* lens, int n_rows, int n_episodes, int window, int heads, int head_dim, void* stream);
 
 /* Fused text-aware visual extraction (otter/policy/models.py:22-36 plus the L2 normalisations of
  * otter.py:195,214): for each (observation m, camera c)
@@ -196,6 +211,11 @@ int otter_repeat_rows(const float* src, long ld_src, float* dst, long ld_dst, in
  * otter/policy/transformer.py:23-24, applied to the cached window at otter.py:325). */
 int otter_add_pe(const float* window, const float* pe, float* out, int batch, int window_len, int n_query, int pos0, int dim,
                  void* stream);
+
+/* Ragged form: out[i, :] = window[e, p, :] + pe[p, :] with e = idx[i], p = lens[e] - 1 (the newest step of each listed
+ * episode; transformer.py:23-24 applied per episode).  idx, lens: device int32. */
+int otter_add_pe_rows(const float* window, const float* pe, float* out, const int* idx, const int* lens, int n_rows,
+                      int n_episodes, int window_len, int dim, void* stream);
 
 /* GPU-resident per-episode window of policy inputs (OTTER.update_cache, otter.py:158-175): appends `fresh[b]` to
  * episode b, dropping the oldest entry once the window is full.  src/dst and lens_in/lens_out are distinct

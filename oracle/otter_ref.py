@@ -197,10 +197,13 @@ def extract_clip_features(images: Tensor, text: Tensor, sd: Dict[str, Tensor], d
 
 
 def forward_encoder(images: Tensor, text: Tensor, proprio: Tensor, sd: Dict[str, Tensor], dims: Dims,
-                    text_mask: Optional[Tensor] = None) -> Tensor:
-    """``otter/policy/otter.py:224-267`` -> transformer input (B, T, transformer_dim)."""
+                    text_mask: Optional[Tensor] = None, clip_features: Optional[Tuple[List[Tensor], Tensor]] = None) -> Tensor:
+    """``otter/policy/otter.py:224-267`` -> transformer input (B, T, transformer_dim).
+
+    ``clip_features`` (what :func:`extract_clip_features` returns) replaces the frozen towers' output: a test can hand in
+    the features another implementation produced and compare only what comes after the towers."""
     b, t = images.shape[:2]
-    per_cam, tf = extract_clip_features(images, text, sd, dims)
+    per_cam, tf = clip_features if clip_features is not None else extract_clip_features(images, text, sd, dims)
     if dims.pool_true_text:
         text_mask = text_mask.repeat_interleave(t, dim=0)
     else:
@@ -219,10 +222,10 @@ def forward_encoder(images: Tensor, text: Tensor, proprio: Tensor, sd: Dict[str,
 
 
 def forward_actions(images: Tensor, text: Tensor, proprio: Tensor, sd: Dict[str, Tensor], dims: Dims,
-                    text_mask: Optional[Tensor] = None) -> Tensor:
+                    text_mask: Optional[Tensor] = None, clip_features=None) -> Tensor:
     """``otter/policy/otter.py:269-291`` -> (B, T, horizon, action_dim)."""
     b, t = images.shape[:2]
-    x = forward_encoder(images, text, proprio, sd, dims, text_mask)
+    x = forward_encoder(images, text, proprio, sd, dims, text_mask, clip_features)
     x = x + sd["pe.pe"][:, :t]
     x = causal_transformer(x, sd, dims.transformer_heads)
     a = action_head(x, sd)
@@ -230,7 +233,7 @@ def forward_actions(images: Tensor, text: Tensor, proprio: Tensor, sd: Dict[str,
 
 
 def forward(images, text: Tensor, proprio: Tensor, sd: Dict[str, Tensor], dims: Dims,
-            gt_actions: Optional[Tensor] = None, camera_keys: Optional[Sequence[str]] = None) -> Tensor:
+            gt_actions: Optional[Tensor] = None, camera_keys: Optional[Sequence[str]] = None, clip_features=None) -> Tensor:
     """``otter/policy/otter.py:339-383`` with ``text`` already tokenised."""
     if isinstance(images, dict):
         keys = sorted(camera_keys if camera_keys is not None else images.keys())
@@ -240,7 +243,7 @@ def forward(images, text: Tensor, proprio: Tensor, sd: Dict[str, Tensor], dims: 
     mask = create_text_mask(text, dims.sot_token, dims.eot_token, dims.first_k_tokens) if dims.pool_true_text else None
     if not torch.is_floating_point(images):
         images = clip_transform(images)
-    actions = forward_actions(images, text, proprio, sd, dims, mask)
+    actions = forward_actions(images, text, proprio, sd, dims, mask, clip_features)
     if gt_actions is None:
         return actions
     if dims.use_mse:

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
@@ -62,6 +62,8 @@ _SIGNATURES = {
     "otter_convert_rows": [_I, _P, _L, _P, _L, _I, _I, _I, _I, _P, _I, _I, _P],
     "otter_repeat_rows": [_P, _L, _P, _L, _I, _I, _I, _P],
     "otter_add_pe": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "otter_add_pe_rows": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "otter_attn_policy_rows": [_P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     "otter_window_append": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "otter_resize_bicubic_u8": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     "otter_action_step": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, c_double, _P],
@@ -112,6 +114,8 @@ def load() -> ctypes.CDLL:
     lib.otter_gemm_workspace_floats.argtypes = [c_int]
     lib.otter_gemm_static_ws_max_n.restype = c_long
     lib.otter_gemm_static_ws_max_n.argtypes = []
+    lib.otter_gemm_static_ws_init.restype = c_int
+    lib.otter_gemm_static_ws_init.argtypes = []
     _lib = lib
     return lib
 
@@ -125,4 +129,5 @@ def call(name: str, *args) -> None:
 
 def exported_names():
     return sorted(list(_SIGNATURES) + ["otter_last_error", "otter_hip_abi_version", "otter_grad_stats_workspace_floats",
-                                            "otter_pos_emb_packed_elems", "otter_gemm_workspace_floats", "otter_gemm_static_ws_max_n"])
+                                            "otter_pos_emb_packed_elems", "otter_gemm_workspace_floats", "otter_gemm_static_ws_max_n",
+                                            "otter_gemm_static_ws_init"])

@@ -12,13 +12,18 @@ deployment this package targets).  Accepted: a ``state_dict`` of TENSORS ONLY, f
   projections concatenated into ``in_proj``, the two projection matrices transposed.
 
 ``torch.save`` files are read with ``torch.load(weights_only=True)`` and safetensors files hold raw tensor bytes: nothing in
-either is executed.  The OpenAI download itself is a TorchScript archive,
-which cannot be opened that way and is deliberately NOT opened here (loading it runs code from the file); whoever
-trusts that file converts it once, elsewhere, with ``torch.save(torch.jit.load(f).state_dict(), out)``.
+either is executed.  The OpenAI download itself (``ViT-L-14.pt``, what ``clip.load`` fetches) is a TorchScript archive: a zip
+of ``data.pkl`` (the pickled module tree), ``code/`` (TorchScript source) and ``data/<n>`` (raw storages).  It is read here
+WITHOUT ``torch.jit.load`` and without running anything from the file (:func:`read_torchscript_archive`): the pickle is walked
+by an unpickler that admits tensor re-assembly and inert containers only, the ``code/`` entries are never opened.
 An OTTER checkpoint needs none of this: it already contains the CLIP tensors.
 """
 from __future__ import annotations
 
+import io
+import pickle
+import zipfile
+from collections import OrderedDict
 from typing import Dict, List, Union
 
 import torch
@@ -27,10 +32,115 @@ import torch
 _NOT_PARAMETERS = ("input_resolution", "context_length", "vocab_size")
 
 
+# ------------------------------------------------------------------------------------------- TorchScript archive, no code run
+_STORAGE_DTYPES = {"HalfStorage": torch.float16, "FloatStorage": torch.float32, "DoubleStorage": torch.float64,
+                   "BFloat16Storage": torch.bfloat16, "LongStorage": torch.int64, "IntStorage": torch.int32,
+                   "ShortStorage": torch.int16, "CharStorage": torch.int8, "ByteStorage": torch.uint8, "BoolStorage": torch.bool}
+
+
+class _StorageType:
+    """Stands for ``torch.<X>Storage`` inside the pickle: carries the element type, constructs nothing."""
+
+    def __init__(self, name: str):
+        self.dtype = _STORAGE_DTYPES[name]
+
+
+class _ScriptObject:
+    """Stands for any ``__torch__.*`` class (a scripted module or one of its sub-objects): keeps the attribute dict, runs no code."""
+
+    def __init__(self):
+        self.state = {}
+
+    def __setstate__(self, state):
+        self.state = state if isinstance(state, dict) else {"__state__": state}
+
+
+def _rebuild_tensor(storage: torch.Tensor, offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
+    size, stride = tuple(int(x) for x in size), tuple(int(x) for x in stride)
+    need = int(offset) + 1 + sum((n - 1) * st for n, st in zip(size, stride)) if all(n > 0 for n in size) else 0
+    if any(n < 0 for n in size) or any(st < 0 for st in stride) or int(offset) < 0 or need > storage.numel():
+        raise pickle.UnpicklingError(f"tensor view (offset {offset}, size {size}, stride {stride}) outside its storage of {storage.numel()}")
+    return storage.as_strided(size, stride, int(offset)).clone()
+
+
+def _identity(x, *_):
+    return x
+
+
+class _TensorsOnlyUnpickler(pickle.Unpickler):
+    """Unpickler for the ``data.pkl`` / ``constants.pkl`` of a TorchScript archive.  ``find_class`` resolves exactly:
+    tensor re-assembly (re-implemented above), storage type markers, ``OrderedDict``, the list builders TorchScript emits, and
+    ``__torch__.*`` names (to an inert attribute holder).  Everything else -- hence any callable from the file -- is refused."""
+
+    def __init__(self, data: bytes, read_storage):
+        super().__init__(io.BytesIO(data))
+        self._read_storage = read_storage
+
+    def find_class(self, module: str, name: str):
+        if module.startswith("__torch__"):
+            return _ScriptObject
+        if module == "torch._utils" and name in ("_rebuild_tensor_v2", "_rebuild_tensor"):
+            return _rebuild_tensor
+        if module == "torch._utils" and name == "_rebuild_parameter":
+            return _identity
+        if module == "torch" and name in _STORAGE_DTYPES:
+            return _StorageType(name)
+        if module == "collections" and name == "OrderedDict":
+            return OrderedDict
+        if module == "torch.jit._pickle" and name in ("build_intlist", "build_tensorlist", "build_doublelist", "build_boollist", "restore_type_tag"):
+            return _identity
+        raise pickle.UnpicklingError(f"refusing to resolve {module}.{name} from a TorchScript archive (tensors and containers only)")
+
+    def persistent_load(self, pid):
+        if not (isinstance(pid, tuple) and len(pid) >= 5 and pid[0] == "storage" and isinstance(pid[1], _StorageType)):
+            raise pickle.UnpicklingError(f"unexpected persistent id {pid!r}")
+        _, stype, key, _location, numel = pid[:5]
+        raw = self._read_storage(str(key))
+        if len(raw) < int(numel) * torch.empty((), dtype=stype.dtype).element_size():
+            raise pickle.UnpicklingError(f"storage {key} holds {len(raw)} bytes, fewer than its {numel} elements need")
+        return torch.frombuffer(bytearray(raw), dtype=stype.dtype, count=int(numel)) if int(numel) else torch.empty(0, dtype=stype.dtype)
+
+
+def is_torchscript_archive(path: str) -> bool:
+    """A zip whose entries include ``<name>/constants.pkl`` or ``<name>/code/``: written by ``torch.jit.save``."""
+    if not zipfile.is_zipfile(path):
+        return False
+    with zipfile.ZipFile(path) as z:
+        return any(n.endswith("/constants.pkl") or "/code/" in n for n in z.namelist())
+
+
+def read_torchscript_archive(path: str) -> Dict[str, torch.Tensor]:
+    """Tensors of a ``torch.jit.save`` archive as a flat ``{dotted.attribute.path: tensor}`` dict (what
+    ``torch.jit.load(path).state_dict()`` holds, plus tensor-valued plain attributes), read without executing anything."""
+    with zipfile.ZipFile(path) as z:
+        names = z.namelist()
+        pkl = [n for n in names if n.endswith("/data.pkl")]
+        if len(pkl) != 1:
+            raise ValueError(f"{path}: expected one data.pkl, found {pkl}")
+        root = pkl[0][: -len("data.pkl")]
+        obj = _TensorsOnlyUnpickler(z.read(pkl[0]), lambda key: z.read(root + "data/" + key)).load()
+    out: Dict[str, torch.Tensor] = {}
+
+    def walk(o, prefix: str):
+        if isinstance(o, torch.Tensor):
+            out[prefix[:-1]] = o
+        elif isinstance(o, _ScriptObject):
+            for k, v in o.state.items():
+                if isinstance(k, str):
+                    walk(v, prefix + k + ".")
+
+    walk(obj, "")
+    if not out:
+        raise ValueError(f"{path}: no tensors found in the archive's module tree")
+    return out
+
+
 def clip_state_dict_from_file(path: str) -> Dict[str, torch.Tensor]:
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         sd = load_file(path, device="cpu")
+    elif is_torchscript_archive(path):
+        sd = read_torchscript_archive(path)
     else:
         sd = torch.load(path, map_location="cpu", weights_only=True)   # raises on anything but plain tensors / containers
     if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):

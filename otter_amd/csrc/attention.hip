@@ -311,6 +311,64 @@ __global__ __launch_bounds__(256) void attn_policy(PolicyAttnArgs p, int total) 
     }
 }
 
+// Ragged cached step: row i is the newest position of episode idx[i] (window position lens[idx[i]] - 1).  Its fresh q|k|v
+// row comes from a compact buffer; the wave stores it into the episode's cache row and attends over the cached rows
+// before it plus the fresh one.  A wave reads only cache rows of earlier positions and writes only its own head's slice
+// of the new row, so the store and the reads of one launch never meet.
+struct PolicyRowsArgs {
+    const float* fresh;    // [n_rows][ldf]: q | k | v of the new positions
+    long ldf;
+    float* cache;          // [n_episodes][S][ld]
+    long ld;
+    float* out;            // [n_rows][ldo]
+    long ldo;
+    const int* idx;
+    const int* lens;
+    int n_episodes, S, heads, hd;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void attn_policy_rows(PolicyRowsArgs p, int total) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= total) return;
+    const int h = w % p.heads, i = w / p.heads;
+    const int dim = p.heads * p.hd;
+    const int e = min(max(p.idx[i], 0), p.n_episodes - 1);
+    const int pos = min(max(p.lens[e] - 1, 0), p.S - 1), nkeys = pos + 1;
+    const float* qrow = p.fresh + (long)i * p.ldf + h * p.hd;
+    const float* knew = qrow + dim;
+    const float* vnew = qrow + 2 * dim;
+    const float* hist = p.cache + (long)e * p.S * p.ld;
+    float* crow = p.cache + ((long)e * p.S + pos) * p.ld + h * p.hd;
+    for (int d = lane; d < p.hd; d += 64) {
+        crow[d] = qrow[d];
+        crow[dim + d] = knew[d];
+        crow[2 * dim + d] = vnew[d];
+    }
+    float sc = -INFINITY;
+    if (lane < nkeys) {
+        const float* krow = (lane == pos) ? knew : hist + (long)lane * p.ld + dim + h * p.hd;
+        float acc = 0.f;
+        for (int d = 0; d < p.hd; d += 4) {
+            const f32x4 a = *(const f32x4*)(qrow + d), k = *(const f32x4*)(krow + d);
+            acc += a[0] * k[0] + a[1] * k[1] + a[2] * k[2] + a[3] * k[3];
+        }
+        sc = acc * p.scale;
+    }
+    const float mx = wave_max(sc);
+    const float ex = (lane < nkeys) ? __expf(sc - mx) : 0.f;
+    const float inv = 1.0f / wave_sum(ex);
+    for (int d = lane; d < p.hd; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < nkeys; ++j) {
+            const float pj = __shfl(ex, j, 64);
+            acc += pj * (j == pos ? vnew[d] : hist[(long)j * p.ld + 2 * dim + h * p.hd + d]);
+        }
+        p.out[(long)i * p.ldo + h * p.hd + d] = acc * inv;
+    }
+}
+
 }  // namespace
 
 template <typename T>
@@ -354,5 +412,24 @@ extern "C" int otter_attn_policy(const float* qkv, long ld, float* out, long ldo
     OTTER_REQUIRE(total < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_attn_policy: grid too large");
     hipLaunchKernelGGL(attn_policy, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, (int)total);
     OTTER_CHECK_LAUNCH("otter_attn_policy");
+    return OTTER_OK;
+}
+
+extern "C" int otter_attn_policy_rows(const float* fresh, long ldf, float* cache, long ld, float* out, long ldo, const int* idx,
+                                      const int* lens, int n_rows, int n_episodes, int window, int heads, int head_dim, void* stream) {
+    OTTER_REQUIRE(fresh && cache && out && idx && lens, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_policy_rows: null operand");
+    if (n_rows == 0) return OTTER_OK;
+    OTTER_REQUIRE(n_rows > 0 && n_episodes > 0 && heads > 0 && head_dim > 0 && window > 0 && window <= 64, OTTER_ERR_UNSUPPORTED_SHAPE,
+                  "otter_attn_policy_rows: bad sizes (window=%d, at most 64)", window);
+    OTTER_REQUIRE(head_dim % 4 == 0 && ld >= 3L * heads * head_dim && ld % 4 == 0 && ldf >= 3L * heads * head_dim && ldf % 4 == 0 &&
+                  ldo >= (long)heads * head_dim, OTTER_ERR_ALIGNMENT,
+                  "otter_attn_policy_rows: head_dim must be a multiple of 4 and the leading dimensions large enough");
+    OTTER_REQUIRE(aligned16(fresh) && aligned16(cache), OTTER_ERR_ALIGNMENT, "otter_attn_policy_rows: buffers must be 16-byte aligned");
+    OTTER_REQUIRE(fresh != cache, OTTER_ERR_INVALID_ARGUMENT, "otter_attn_policy_rows: the fresh rows and the cache must be different buffers");
+    PolicyRowsArgs a{fresh, ldf, cache, ld, out, ldo, idx, lens, n_episodes, window, heads, head_dim, 1.0f / sqrtf((float)head_dim)};
+    const long total = (long)n_rows * heads;
+    OTTER_REQUIRE(total < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_attn_policy_rows: grid too large");
+    hipLaunchKernelGGL(attn_policy_rows, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, (int)total);
+    OTTER_CHECK_LAUNCH("otter_attn_policy_rows");
     return OTTER_OK;
 }

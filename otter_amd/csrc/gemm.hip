@@ -351,25 +351,44 @@ constexpr int STATIC_WS_MAX_N = 4096;
 constexpr long STATIC_WS_FLOATS = 8L * 255 * STATIC_WS_MAX_N;      // == otter_gemm_workspace_floats(4096): 33.4 MB
 static __device__ __align__(256) float scratch[STATIC_WS_FLOATS];
 
-static float* static_scratch_of_current_device() {
+// -> the current device's copy of `scratch` (looked up on the device's first call, under a lock), or nullptr with the error
+// text set.  `stream`'s device must be the current one: the pointer is that device's, and so is the launch.
+static float* static_scratch_of_current_device(hipStream_t stream, const char* who) {
     static std::mutex mu;
     static std::map<int, float*> per_device;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
-        otter_set_error("otter_gemm_static_ws: no current HIP device");
+        otter_set_error("%s: no current HIP device", who);
         return nullptr;
+    }
+    if (stream) {
+        int sdev = -1;
+        if (hipStreamGetDevice(stream, &sdev) != hipSuccess || sdev != dev) {
+            otter_set_error("%s: the stream belongs to device %d, the current device is %d (make the stream's device current)", who, sdev, dev);
+            return nullptr;
+        }
     }
     std::lock_guard<std::mutex> lock(mu);
     auto it = per_device.find(dev);
     if (it != per_device.end()) return it->second;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        otter_set_error("%s: first use on device %d while the stream is being captured: call otter_gemm_static_ws_init() on this device "
+                        "before the capture (the symbol lookup may load the code object, which a capture does not allow)", who, dev);
+        return nullptr;
+    }
     float* ptr = nullptr;
     const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !ptr) {
-        otter_set_error("otter_gemm_static_ws: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+        otter_set_error("%s: hipGetSymbolAddress(scratch) failed on device %d: %s", who, dev, hipGetErrorString(e));
         return nullptr;
     }
     per_device[dev] = ptr;
     return ptr;
+}
+
+extern "C" int otter_gemm_static_ws_init(void) {
+    return static_scratch_of_current_device(nullptr, "otter_gemm_static_ws_init") ? OTTER_OK : OTTER_ERR_LAUNCH;
 }
 
 extern "C" long otter_gemm_static_ws_max_n(void) { return STATIC_WS_MAX_N; }
@@ -382,7 +401,7 @@ extern "C" int otter_gemm_static_ws(int dtype, const void* A, long lda, const vo
     OTTER_REQUIRE(N <= STATIC_WS_MAX_N, OTTER_ERR_UNSUPPORTED_SHAPE,
                   "otter_gemm_static_ws: N=%d exceeds the static scratch (N <= %d); use otter_gemm_ws with a caller-provided workspace", N,
                   STATIC_WS_MAX_N);
-    float* ws = static_scratch_of_current_device();
+    float* ws = static_scratch_of_current_device((hipStream_t)stream, "otter_gemm_static_ws");
     if (!ws) return OTTER_ERR_LAUNCH;
     // (the split-K pass writes every partial product it later reads, so the scratch needs no clearing between calls)
     return gemm_impl(dtype, A, lda, W, n_pad, bias, residual, ldr, C, ldc, M, N, K, epilogue, row_stats, col_sum, ws, STATIC_WS_FLOATS, stream);

@@ -155,6 +155,18 @@ __global__ __launch_bounds__(256) void add_pe_kernel(const float* window, const 
     for (int c = threadIdx.x; c < dim; c += 256) out[(long)row * dim + c] = src[c] + p[c];
 }
 
+// Ragged form for episodes that are at different positions: row i belongs to episode idx[i], whose newest input sits at window
+// position lens[idx[i]] - 1 (lens: the lengths AFTER the append of this step).
+__global__ __launch_bounds__(256) void add_pe_rows_kernel(const float* window, const float* pe, float* out, const int* idx, const int* lens,
+                                                          int n_episodes, int S, int dim) {
+    const int row = blockIdx.x;
+    const int e = min(max(idx[row], 0), n_episodes - 1);
+    const int pos = min(max(lens[e] - 1, 0), S - 1);
+    const float* src = window + ((long)e * S + pos) * dim;
+    const float* p = pe + (long)pos * dim;
+    for (int c = threadIdx.x; c < dim; c += 256) out[(long)row * dim + c] = src[c] + p[c];
+}
+
 // Rollout window of policy inputs, one per episode (the reference's cached_transformer_input):
 //   len < S : dst = src with `fresh` written at position len      (new length len+1)
 //   len = S : dst = src shifted left by one, `fresh` at S-1       (length stays S)
@@ -277,6 +289,16 @@ extern "C" int otter_add_pe(const float* window, const float* pe, float* out, in
                   "otter_add_pe: positions %d..%d outside the window of %d", pos0, pos0 + n_query - 1, window_len);
     hipLaunchKernelGGL(add_pe_kernel, dim3(batch * n_query), dim3(256), 0, (hipStream_t)stream, window, pe, out, window_len, n_query, pos0, dim);
     OTTER_CHECK_LAUNCH("otter_add_pe");
+    return OTTER_OK;
+}
+
+extern "C" int otter_add_pe_rows(const float* window, const float* pe, float* out, const int* idx, const int* lens, int n_rows,
+                                 int n_episodes, int window_len, int dim, void* stream) {
+    OTTER_REQUIRE(window && pe && out && idx && lens, OTTER_ERR_INVALID_ARGUMENT, "otter_add_pe_rows: null operand");
+    if (n_rows == 0) return OTTER_OK;
+    OTTER_REQUIRE(n_rows > 0 && n_episodes > 0 && window_len > 0 && dim > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_add_pe_rows: bad sizes");
+    hipLaunchKernelGGL(add_pe_rows_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, window, pe, out, idx, lens, n_episodes, window_len, dim);
+    OTTER_CHECK_LAUNCH("otter_add_pe_rows");
     return OTTER_OK;
 }
 

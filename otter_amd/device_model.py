@@ -258,6 +258,22 @@ class PolicyDevice:
             ops.gemm(m, blk.w_proj, blk.width, blk.b_proj, residual=x, out=x)
         return x
 
+    def run_rows(self, window: Tensor, cache: List[Tensor], idx: Tensor, lens: Tensor) -> Tensor:
+        """The newest position of the episodes listed in ``idx`` (int32, device), each at its own window position
+        ``lens[e] - 1`` (``lens``: int32 (B,), lengths after this step's append): only those rows are computed, their K/V are
+        stored into ``cache`` and earlier positions are read from it.  Returns fp32 (len(idx), dim)."""
+        x = ops.add_pe_rows(window, self.pe, idx, lens)
+        f32 = torch.float32
+        for blk, kv in zip(self.layers, cache):
+            h = ops.layernorm(x, *blk.ln1, out_dtype=f32)
+            fresh = ops.gemm(h, blk.wqkv, blk.n_qkv, blk.bqkv)
+            a = ops.attn_policy_rows(fresh, kv, idx, lens, self.heads)
+            ops.gemm(a, blk.wo, blk.width, blk.bo, residual=x, out=x)
+            h = ops.layernorm(x, *blk.ln2, out_dtype=f32)
+            m = ops.gemm(h, blk.w_fc, blk.n_fc, blk.b_fc, act=ops.ACT_GELU)
+            ops.gemm(m, blk.w_proj, blk.width, blk.b_proj, residual=x, out=x)
+        return x
+
     def head(self, x: Tensor, pick: Optional[Tensor] = None, group: int = 1, pick_bias: int = 0) -> Tensor:
         """x fp32 (R, dim) -> fp32 (R or R/group, horizon*action_dim); ``pick`` (+bias) selects one row per group."""
         a = ops.convert_rows(x, pick=pick, group=group, pick_bias=pick_bias) if pick is not None else x

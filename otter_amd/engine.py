@@ -11,8 +11,10 @@ engine relies on:
 * once the window is full every call drops the oldest input and all positions shift by one, so K/V of every
   remaining step change: the window is recomputed ("full" mode; at most ``seq_length`` tokens per episode).
 
-Episodes advance in lock-step; ``reset(episode_ids)`` of a subset switches the engine to full mode with
-per-episode lengths (rows past an episode's length are zero and, by causality, never influence earlier rows).
+Both conditions hold per episode, so the engine keeps lengths and cache validity per episode: episodes that were reset
+at different times sit at different window positions and still take the cached step (``otter.py:153-175`` semantics for
+each of them), while the ones whose windows slide are recomputed (rows past an episode's length are zero and, by
+causality, never influence earlier rows).
 """
 from __future__ import annotations
 
@@ -71,6 +73,17 @@ class _EncodeGraph:
 
 
 class BatchedRollout:
+    """``n`` concurrent episodes.  Every episode has its own length and its own cache state:
+
+    * an episode whose window is not full yet and whose K/V rows are valid takes the CACHED step: only its new position is
+      computed, at that episode's own window position (episodes that started at different times sit at different ones);
+    * an episode whose window is full (it slides from now on: every position shifts) or whose K/V rows were never produced
+      (history handed over with :meth:`adopt` or written through ``OTTER.update_cache``) takes the RECOMPUTE step.
+
+    A step in which every episode is cached at one common position, or every episode recomputes, runs over the whole
+    batch with no gather; a mixed step runs the two groups one after the other on their own rows.  ``reset(ids)`` of a
+    subset therefore never takes the K/V cache away from the other episodes."""
+
     def __init__(self, dev: OtterDevice, n_episodes: int):
         self.dev, self.n = dev, int(n_episodes)
         self.S = dev.seq_length
@@ -80,8 +93,10 @@ class BatchedRollout:
         self._cur = 0
         self._cache = dev.policy.new_cache(self.n, self.S)
         self.lens_host = np.zeros(self.n, dtype=np.int64)
-        self._lockstep = True
+        self.kv_ok = np.ones(self.n, dtype=bool)       # K/V rows [0, len) of the episode are valid at their current positions
         self._graph: Optional[_EncodeGraph] = None
+        self._idx_cache: dict = {}                     # episode subsets already uploaded as device index tensors
+        self.last_mode = ""                            # "cached", "recompute" or "mixed": what the last step ran (tests, logs)
 
     # ------------------------------------------------------------------ state
     @property
@@ -96,15 +111,46 @@ class BatchedRollout:
             for l in self._lens:
                 l.zero_()
             self.lens_host[:] = 0
-            self._lockstep = True
+            self.kv_ok[:] = True
             return
-        ids = torch.as_tensor(list(episode_ids), dtype=torch.long, device=self.dev.device)
-        if ids.numel() == 0:
+        ids_list = [int(e) for e in episode_ids]
+        if not ids_list:
             return
+        if min(ids_list) < 0 or max(ids_list) >= self.n:
+            raise IndexError(f"reset: episode ids must lie in [0, {self.n})")
+        ids = torch.as_tensor(ids_list, dtype=torch.long, device=self.dev.device)
         self._win[self._cur].index_fill_(0, ids, 0.0)
         self._lens[self._cur].index_fill_(0, ids, 0)
-        self.lens_host[list(episode_ids)] = 0
-        self._lockstep = bool(np.all(self.lens_host == 0))
+        self.lens_host[ids_list] = 0
+        self.kv_ok[ids_list] = True                    # an empty history is trivially valid
+
+    def invalidate_kv(self, episode_ids: Optional[Sequence[int]] = None) -> None:
+        """The windows were written by someone else (no K/V rows exist for them): recompute until the next reset."""
+        if episode_ids is None:
+            self.kv_ok[:] = False
+        else:
+            self.kv_ok[[int(e) for e in episode_ids]] = False
+
+    def adopt(self, other: "BatchedRollout") -> None:
+        """Take over the running episodes of ``other`` (same episode count, window and width): their windows and lengths are
+        copied, their K/V rows -- products of other weights -- are not."""
+        if (other.n, other.S, other.dev.dim) != (self.n, self.S, self.dev.dim):
+            raise ValueError("adopt: the two rollouts differ in episode count, window length or width")
+        self._win[self._cur].copy_(other._win[other._cur])
+        self._lens[self._cur].copy_(other._lens[other._cur])
+        self.lens_host[:] = other.lens_host
+        self.kv_ok[:] = other.lens_host == 0
+
+    def _index(self, ids: np.ndarray):
+        """Device (int32, int64) index tensors of an episode subset; subsets repeat from step to step, so they are kept."""
+        key = ids.tobytes()
+        hit = self._idx_cache.get(key)
+        if hit is None:
+            if len(self._idx_cache) > 256:
+                self._idx_cache.clear()
+            t = torch.from_numpy(ids.astype(np.int32)).to(self.dev.device)
+            hit = self._idx_cache[key] = (t, t.long())
+        return hit
 
     # ------------------------------------------------------------------ one observation per episode
     def step(self, images: Tensor, text_feats: Tensor, proprio: Tensor, text_mask: Optional[Tensor] = None) -> Tensor:
@@ -122,17 +168,36 @@ class BatchedRollout:
         nxt = self._cur ^ 1
         ops.window_append(self._win[self._cur], fresh, self._win[nxt], self._lens[self._cur], self._lens[nxt])
         self._cur = nxt
-        was_full = self.lens_host >= self.S
-        self.lens_host = np.minimum(self.lens_host + 1, self.S)
-        win = self._win[self._cur]
-        if self._lockstep and not was_full[0]:
-            pos = int(self.lens_host[0]) - 1
-            y = dev.policy.run(win, self._cache, 1, pos)                         # (n, dim): only the new position
-            out = dev.policy.head(y)
-        else:
-            y = dev.policy.run(win, self._cache, self.S, 0)                      # whole window, (n*S, dim)
-            if self._lockstep:
-                out = dev.policy.head(y.view(self.n, self.S, dev.dim)[:, self.S - 1, :])
+        before = self.lens_host
+        cached = (before < self.S) & self.kv_ok                                  # per episode: only the new position is needed
+        self.lens_host = np.minimum(before + 1, self.S)
+        win, lens = self._win[self._cur], self._lens[self._cur]
+        pol = dev.policy
+        if cached.all() and (before == before[0]).all():
+            # every episode at the same position: the new row of every episode, in place, no index
+            self.last_mode = "cached"
+            y = pol.run(win, self._cache, 1, int(before[0]))                     # (n, dim)
+            out = pol.head(y)
+        elif not cached.any():
+            # whole windows of every episode; rows past an episode's length are zero and, by causality, touch nothing before them
+            self.last_mode = "recompute"
+            y = pol.run(win, self._cache, self.S, 0)                             # (n*S, dim)
+            if (self.lens_host == self.S).all():
+                out = pol.head(y.view(self.n, self.S, dev.dim)[:, self.S - 1, :])
             else:
-                out = dev.policy.head(y, pick=self._lens[self._cur], group=self.S, pick_bias=-1)   # row len-1 of each window
+                out = pol.head(y, pick=lens, group=self.S, pick_bias=-1)         # row len-1 of each window
+            self.kv_ok |= before < self.S      # the rows just written stay valid until the episode's window slides
+        else:
+            # episodes at different positions, or some cached and some recomputing: each group on its own rows
+            ids_c, ids_f = np.flatnonzero(cached), np.flatnonzero(~cached)
+            self.last_mode = "mixed" if ids_f.size else "cached"
+            out = torch.empty(self.n, dev.horizon * dev.action_dim, dtype=torch.float32, device=dev.device)
+            i32, i64 = self._index(ids_c)
+            out.index_copy_(0, i64, pol.head(pol.run_rows(win, self._cache, i32, lens)))
+            if ids_f.size:
+                i32, i64 = self._index(ids_f)
+                win_f = win.index_select(0, i64)
+                lens_f = lens.index_select(0, i64)
+                y = pol.run(win_f, pol.new_cache(ids_f.size, self.S), self.S, 0)     # a scratch cache: these rows are not kept
+                out.index_copy_(0, i64, pol.head(y, pick=lens_f, group=self.S, pick_bias=-1))
         return out.view(self.n, dev.horizon, dev.action_dim)

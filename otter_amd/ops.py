@@ -478,6 +478,44 @@ def add_pe(window: Tensor, pe: Tensor, n_query: int, pos0: int) -> Tensor:
     return out
 
 
+def _rows_index(idx: Tensor, lens: Tensor, n_episodes: int, name: str) -> int:
+    _chk(idx, torch.int32, name + ".idx", 1)
+    _chk(lens, torch.int32, name + ".lens", 1)
+    if lens.numel() != n_episodes or not idx.is_contiguous() or not lens.is_contiguous():
+        raise ValueError(f"{name}: lens must hold one length per episode ({n_episodes}), idx / lens contiguous")
+    return idx.numel()
+
+
+def add_pe_rows(window: Tensor, pe: Tensor, idx: Tensor, lens: Tensor) -> Tensor:
+    """Newest step of each listed episode plus its positional row: window (B, S, dim), idx int32 (n,) episode numbers,
+    lens int32 (B,) lengths after this step's append -> fp32 (n, dim)."""
+    _chk(window, torch.float32, "add_pe_rows.window", 3)
+    _chk(pe, torch.float32, "add_pe_rows.pe", 2)
+    b, s, dim = window.shape
+    n = _rows_index(idx, lens, b, "add_pe_rows")
+    if not window.is_contiguous() or not pe.is_contiguous() or pe.shape[1] != dim or pe.shape[0] < s:
+        raise ValueError("add_pe_rows: shape mismatch (the positional table must cover the window)")
+    out = torch.empty(n, dim, dtype=torch.float32, device=window.device)
+    _lib.call("otter_add_pe_rows", _ptr(window), _ptr(pe), _ptr(out), _ptr(idx), _ptr(lens), n, b, s, dim, _stream())
+    return out
+
+
+def attn_policy_rows(fresh: Tensor, qkv_cache: Tensor, idx: Tensor, lens: Tensor, heads: int) -> Tensor:
+    """fresh fp32 (n, 3*dim) q|k|v of the newest step of episodes idx; qkv_cache (B, S, 3*dim) receives them at each
+    episode's position lens[e] - 1 -> attention outputs fp32 (n, dim)."""
+    _chk(fresh, torch.float32, "attn_policy_rows.fresh", 2)
+    _chk(qkv_cache, torch.float32, "attn_policy_rows.cache", 3)
+    b, s, w3 = qkv_cache.shape
+    dim = w3 // 3
+    n = _rows_index(idx, lens, b, "attn_policy_rows")
+    if not qkv_cache.is_contiguous() or dim * 3 != w3 or dim % heads != 0 or tuple(fresh.shape) != (n, w3):
+        raise ValueError(f"attn_policy_rows: cache {tuple(qkv_cache.shape)}, fresh {tuple(fresh.shape)}, {n} rows, {heads} heads")
+    _, _, ldf = _rows_view(fresh, "attn_policy_rows.fresh")
+    out = torch.empty(n, dim, dtype=torch.float32, device=fresh.device)
+    _lib.call("otter_attn_policy_rows", _ptr(fresh), ldf, _ptr(qkv_cache), w3, _ptr(out), dim, _ptr(idx), _ptr(lens), n, b, s, heads, dim // heads, _stream())
+    return out
+
+
 def window_append(src: Tensor, fresh: Tensor, dst: Tensor, lens_in: Tensor, lens_out: Tensor) -> None:
     _chk(src, torch.float32, "window.src", 3)
     _chk(dst, torch.float32, "window.dst", 3)

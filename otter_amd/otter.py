@@ -99,7 +99,8 @@ class OTTER(nn.Module):
         ``p.mul_``: the version counter) or re-pointed (``p.data = other``: the storage address); moves and
         ``load_state_dict`` drop the packed copies directly.  Writes THROUGH ``p.data`` / ``p.detach()`` (``p.data.copy_()``,
         an EMA ``p.data.mul_()``) or through raw pointers change neither: call :meth:`invalidate_device_weights` after them,
-        or set ``check_weights_by_value`` to have every forward compare a checksum of the values.  Buffers that the device
+        or set ``check_weights_by_value`` to have every forward compare a fingerprint of the values (per-tensor sum and sum
+        of squares: a heuristic that catches optimizer-style writes, not a proof of equality).  Buffers that the device
         model packs (``pe.pe``, ``visual_extraction.*.pos_emb``) are part of the trainable group's key.  Called on every
         forward: the tensor lists are cached (the module tree is fixed after construction) so that the check costs two
         attribute reads per tensor."""
@@ -110,7 +111,11 @@ class OTTER(nn.Module):
         group = self._param_groups[1 if trainable else 0]
         key = tuple(p._version for p in group) + tuple(p.data_ptr() for p in group)
         if self.check_weights_by_value:
-            key += (float(torch.stack([p.detach().double().sum() for p in group]).sum().item()),)
+            # per tensor: sum and sum of squares in fp64, weighted by the tensor's index -- a heuristic fingerprint, not a
+            # comparison of every value: it sees scaling, sign flips, zero-mean perturbations and writes to one tensor that
+            # a plain sum over everything would miss, but not, e.g., two rows of one tensor swapping places
+            vals = [torch.stack([p.detach().double().sum(), p.detach().double().square().sum()]) * (i + 1) for i, p in enumerate(group)]
+            key += tuple(torch.stack(vals).sum(0).tolist())
         return key
 
     def invalidate_device_weights(self, towers: bool = True, keep_history: bool = True) -> None:
@@ -118,8 +123,13 @@ class OTTER(nn.Module):
         from the module's tensors.  For writers the automatic check cannot see: in-place writes through ``p.data`` /
         ``p.detach()``, raw-pointer kernels (the device AdamW of :class:`otter_amd.trainer.Trainer`).  ``towers=False``
         keeps the packed CLIP towers (0.86 GB; only the trainable modules changed).  ``keep_history`` carries the running
-        episode's window of policy inputs over to the new weights."""
-        self._carry_window = self._window_snapshot() if keep_history else None
+        episode's window of policy inputs over to the new weights (also across several invalidations with no inference
+        call between them: the window taken at the first one is kept)."""
+        if not keep_history:
+            self._carry_window = None
+        elif self._rollout is not None:
+            self._carry_window = self._window_snapshot()
+        # else: no live rollout -- whatever an earlier invalidation carried stays
         self._dev = None
         if towers:
             self._clip_dev = None
@@ -161,6 +171,8 @@ class OTTER(nn.Module):
                 clip_dtype=self.clip_compute_dtype, clip=clip)
             self._dev_key = key
             self._rollout = None
+            if self._tail is not None:
+                self._tail._dims_key = None               # the training tail packs the same buffers (pe, pos_emb): repack them too
         return self._dev
 
     # ------------------------------------------------------------------ rollout cache (otter.py:153-175)
@@ -264,7 +276,7 @@ class OTTER(nn.Module):
             ops.window_append(ro._win[ro._cur], x[:, i].contiguous(), ro._win[nxt], ro._lens[ro._cur], ro._lens[nxt])
             ro._cur = nxt
             ro.lens_host[:] = min(int(ro.lens_host[0]) + 1, ro.S)
-        ro._lockstep = False          # K/V history was not produced for these rows: recompute the window
+        ro.invalidate_kv()            # K/V history was not produced for these rows: recompute the window
         self.cache_size = int(ro.lens_host[0])
 
     @torch.no_grad()

@@ -90,7 +90,9 @@ class BatchedRolloutPolicy:
     """Many robots / simulated episodes behind one model: frames, poses and grippers of ``n`` episodes in, ``n`` 7-d robot
     actions out per control step.  The encoder, the policy with its GPU-resident history, the absolute-action decode, the
     action queue and the 10-d -> 7-d conversion all run on the device; per step the host uploads frames + poses and reads
-    back (n, 7) doubles."""
+    back (n, 7) doubles.  The packed weights follow the model: every call asks it for its current device copy (as
+    ``OTTER.forward_inference`` does), and when that changed -- an optimizer step, ``load_state_dict``,
+    ``invalidate_device_weights()`` -- the running episodes' windows move over to the new weights."""
 
     def __init__(self, model, n_episodes: int, action_exec_horizon: int, receding_horizon_control: bool = False):
         from .engine import BatchedRollout
@@ -106,11 +108,21 @@ class BatchedRolloutPolicy:
         self.rollout.reset(episode_ids)
         self.queue.clear(episode_ids)
 
+    def refresh(self) -> None:
+        """Pick up the model's current packed weights (a no-op while they are unchanged)."""
+        from .engine import BatchedRollout
+        dev = self.model.device_model()
+        if dev is not self.dev:
+            fresh = BatchedRollout(dev, self.n)
+            fresh.adopt(self.rollout)              # policy inputs of the running episodes are kept, K/V rows are recomputed
+            self.dev, self.rollout = dev, fresh
+
     def __call__(self, frames, token_ids, cartesian: np.ndarray, gripper: np.ndarray):
         """frames uint8 (n*cams, 3, R, R) on the device (camera order = sorted camera keys; :func:`vision_tf.crop_resize_device`
         makes them from raw camera frames), token_ids int32 (n, 77) on the host, cartesian (n, 6), gripper (n,) ->
         robot actions fp64 (n, 7) on the device."""
         import torch
+        self.refresh()
         pose = torch.from_numpy(poses_to_proprio(cartesian, gripper)).to(self.dev.device)
         text = self.dev.clip.text_tokens_cached(token_ids)
         chunks = self.rollout.step(frames, text, pose.float())

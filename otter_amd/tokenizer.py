@@ -12,14 +12,18 @@ Restates the published algorithm of OpenAI CLIP's ``SimpleTokenizer`` / ``clip.t
   longer inputs.
 
 The merges file is not redistributed here and the reference does not vendor it either; pass its path or set
-``OTTER_CLIP_BPE`` (plain text or ``.gz``).  ``ftfy.fix_text`` (a mojibake repair step of the original) is applied
-when ``ftfy`` is installed; for text it leaves unchanged (all ordinary ASCII prompts) the ids are identical either way.
+``OTTER_CLIP_BPE`` (plain text or ``.gz``).  ``ftfy.fix_text`` (the original's first clean-up step: mojibake repair, NFC
+normalisation, curly quotes -> straight quotes, ...) is applied when ``ftfy`` is installed.  It leaves plain ASCII text
+unchanged, so ASCII prompts get identical ids either way; for text with any non-ASCII character the ids may differ from
+``clip.tokenize`` when ``ftfy`` is missing, and the tokenizer says so instead of diverging silently: a
+:class:`UnrepairedTextWarning` once per process, or a ``RuntimeError`` with ``OTTER_TOKENIZER_STRICT=1``.
 """
 from __future__ import annotations
 
 import gzip
 import html
 import os
+import warnings
 from functools import lru_cache
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
@@ -52,12 +56,28 @@ def bytes_to_unicode() -> Dict[int, str]:
     return ordered
 
 
+class UnrepairedTextWarning(UserWarning):
+    """A prompt with non-ASCII characters was tokenised without ``ftfy.fix_text``: its ids may differ from ``clip.tokenize``."""
+
+
+_warned_unrepaired = False
+
+
 def _clean(text: str) -> str:
+    global _warned_unrepaired
     try:
         import ftfy  # type: ignore
         text = ftfy.fix_text(text)
     except ImportError:
-        pass
+        if not text.isascii():
+            msg = ("prompt contains non-ASCII characters and the `ftfy` package is not installed: clip.tokenize repairs such text with "
+                   "ftfy.fix_text before encoding it, so the token ids produced here may differ from the reference's "
+                   f"(first such prompt: {text[:60]!r}); install ftfy for bit-exact ids")
+            if os.environ.get("OTTER_TOKENIZER_STRICT", "0") == "1":
+                raise RuntimeError(msg)
+            if not _warned_unrepaired:
+                _warned_unrepaired = True
+                warnings.warn(msg, UnrepairedTextWarning, stacklevel=3)
     text = html.unescape(html.unescape(text)).strip()
     return re.sub(r"\s+", " ", text).strip()
 

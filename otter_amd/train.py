@@ -73,9 +73,16 @@ class Tape:
     def record(self, fn: Callable[[], None]) -> None:
         self._steps.append(fn)
 
-    def backward(self) -> None:
-        for fn in reversed(self._steps):
-            fn()
+    def __len__(self) -> int:
+        return len(self._steps)
+
+    def backward(self, on_step: Optional[Callable[[int], None]] = None) -> None:
+        """Replay the closures last to first; ``on_step(i)`` runs after closure i (every closure recorded at or after
+        position i has then run: the gradients of whatever was first used at i or later are final)."""
+        for i in range(len(self._steps) - 1, -1, -1):
+            self._steps[i]()
+            if on_step is not None:
+                on_step(i)
         self._steps.clear()
 
 
@@ -188,13 +195,17 @@ class TrainableTail:
         # loaded by OtterInference) takes part in the forward pass and simply gets no gradient buffer
         self.params: Dict[str, torch.nn.Parameter] = {n: p for n, p in model.named_parameters() if not n.startswith("clip_model.")}
         self.buffers = dict(model.named_buffers())
+        self._tape: Optional[Tape] = None
+        self.first_use: Dict[str, int] = {}       # parameter name -> tape position at its first use in the running forward pass
 
     def trainable_names(self) -> List[str]:
         return [n for n, p in self.params.items() if p.requires_grad]
 
     def _dims(self, device, clip_dtype):
         """Sizes and constant tables (cached): pooled widths, transposed pos_emb tables, the window positional table."""
-        key = (device, clip_dtype)
+        # the packed tables follow their source buffers: in-place writes bump the version, re-pointing changes the address
+        packed = [b for n, b in self.buffers.items() if n == "pe.pe" or n.endswith(".pos_emb")]
+        key = (device, clip_dtype, tuple((b._version, b.data_ptr()) for b in packed))
         if getattr(self, "_dims_key", None) != key:
             from types import SimpleNamespace
             m = self.model
@@ -212,6 +223,8 @@ class TrainableTail:
     # -- parameter access ------------------------------------------------------------------------------------------
     def _var(self, grads: Dict[str, Tensor], name: str, shape2d: Optional[Tuple[int, int]] = None) -> Var:
         """The parameter as a tape variable; it collects a gradient iff ``grads`` holds a buffer for it."""
+        if self._tape is not None:
+            self.first_use.setdefault(name, len(self._tape))
         t = self.params[name].detach()
         g = grads.get(name)
         if shape2d is not None:
@@ -264,22 +277,26 @@ class TrainableTail:
             # the copy-back closure must run BEFORE the LN backward, i.e. be recorded after it: it is.
 
     def forward_backward(self, images: Tensor, tokens_host: Tensor, proprio: Tensor, gt_actions: Tensor, text_mask: Optional[Tensor],
-                         grads: Optional[Dict[str, Tensor]], grad_scale: float = 1.0) -> Tensor:
+                         grads: Optional[Dict[str, Tensor]], grad_scale: float = 1.0, exchange=None) -> Tensor:
         """images (B, T, cams, 3, R, R) uint8 / fp32 on the device; tokens (B, ctx) int32 on the host; proprio (B, T, P_in);
         gt_actions (B, T, horizon, action_dim).  With ``grads`` (name -> zero-initialised fp32 buffer) the gradients of
-        ``grad_scale * loss`` are accumulated into it.  Returns the loss as a (1,) device tensor."""
+        ``grad_scale * loss`` are accumulated into it.  ``exchange`` (a :class:`otter_amd.trainer.BucketedExchange`) is told,
+        while the backward pass runs, which parameters' gradients are final, so that the ranks' gradient exchange overlaps
+        the rest of the pass (what DistributedDataParallel's bucket hooks do, ``script/train.py:116-119``).
+        Returns the loss as a (1,) device tensor."""
         if grads is None:
             return self._forward_backward(images, tokens_host, proprio, gt_actions, text_mask, grads, grad_scale)
         arena = _GradArena(images.device, getattr(self, "_arena_hint", 0))
         _arena_tls.arena = arena
         try:
-            return self._forward_backward(images, tokens_host, proprio, gt_actions, text_mask, grads, grad_scale)
+            return self._forward_backward(images, tokens_host, proprio, gt_actions, text_mask, grads, grad_scale, exchange)
         finally:
             _arena_tls.arena = None
+            self._tape = None
             self._arena_hint = arena.used
 
     def _forward_backward(self, images: Tensor, tokens_host: Tensor, proprio: Tensor, gt_actions: Tensor, text_mask: Optional[Tensor],
-                          grads: Optional[Dict[str, Tensor]], grad_scale: float = 1.0) -> Tensor:
+                          grads: Optional[Dict[str, Tensor]], grad_scale: float = 1.0, exchange=None) -> Tensor:
         model = self.model
         clip = model.clip_device()
         dm = self._dims(clip.device, clip.dtype)
@@ -289,6 +306,7 @@ class TrainableTail:
         want = grads is not None
         G = grads if want else {}                                                   # no buffers: nothing collects a gradient
         tape = Tape()
+        self._tape, self.first_use = tape, {}
         device = clip.device
 
         # ---- frozen towers (no gradient) ----
@@ -362,9 +380,13 @@ class TrainableTail:
         gt = gt_actions.to(device, torch.float32).reshape(m, -1).contiguous()
         loss, dpred = ops.loss_fwd_bwd(pred.t, gt, model.use_mse, grad_scale, want_grad=want)
         if not want:
+            self._tape = None
             return loss
         pred.g = dpred
-        tape.backward()
+        if exchange is not None:
+            # the temperatures get their gradient after the tape (below): their buckets go out last
+            exchange.begin({n: i for n, i in self.first_use.items() if not n.endswith(".temperature")})
+        tape.backward(None if exchange is None else exchange.after_step)
         # temperature: the only trainable input of the fused extraction kernel
         pos = torch.stack([self.buffers[f"visual_extraction.{c}.pos_emb"].detach().float() for c in range(cams)]).contiguous()
         part = ops.text_aware_pool_temperature_grad(tokens, tf_raw, pos, temperature, ta_g, m, cams, t, n_patches=p)
@@ -373,6 +395,8 @@ class TrainableTail:
         for c in range(cams):
             if f"visual_extraction.{c}.temperature" in grads:
                 ops.add_inplace(grads[f"visual_extraction.{c}.temperature"].view(1), tg[c:c + 1])
+        if exchange is not None:
+            exchange.finish()
         return loss
 
 

@@ -93,6 +93,64 @@ def allreduce_flat(flat: Tensor, bucket_elems: int = 8 << 20) -> None:
         w.wait()
 
 
+class BucketedExchange:
+    """Gradient exchange overlapped with the backward pass.
+
+    The flat gradient buffer is cut into buckets of ``bucket_elems`` elements.  A bucket's SUM all-reduce is launched (async,
+    on the collective library's own stream) as soon as every parameter that has elements in it is final -- the backward
+    tape reports its progress through :meth:`after_step` -- so the exchange of the layers that finish first runs beside
+    the backward kernels of the rest, as DistributedDataParallel's bucket hooks do (``script/train.py:116-119``,
+    ``otter/util/misc.py:335``).  Parameters are laid out in forward order and finish in reverse order: the buckets at the
+    end of the buffer go first.  :meth:`finish` launches what is left (parameters whose gradient is produced after the
+    tape, parameters the pass never touched), :meth:`wait` makes the current stream wait for all of them.
+
+    Without a process group (or on one rank, unless ``single_rank`` asks for the collectives anyway: a rehearsal of the
+    RCCL path on a one-GPU box) every method is a no-op."""
+
+    def __init__(self, flat: Tensor, where: Dict[str, Tuple[int, int]], bucket_elems: int = 8 << 20, single_rank: bool = False):
+        self.flat = flat
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank)
+        self.bounds = bucket_bounds(flat.numel(), bucket_elems)
+        # names with elements in each bucket (a parameter may straddle two buckets)
+        self.members: List[List[str]] = [[n for n, (a, b) in where.items() if a < hi and b > lo] for lo, hi in self.bounds]
+        self.ready_at: List[int] = []
+        self.launched: List[bool] = []
+        self.works: list = []
+        self.order: List[int] = []           # bucket indices in launch order (for tests and logs)
+
+    def begin(self, first_use: Dict[str, int]) -> None:
+        """``first_use``: parameter name -> tape position of its first use; a parameter that is not listed counts as never
+        final before :meth:`finish`."""
+        self.ready_at = [min((first_use.get(n, -1) for n in names), default=-1) for names in self.members]
+        self.launched = [False] * len(self.bounds)
+        self.works, self.order = [], []
+
+    def _launch(self, b: int) -> None:
+        self.launched[b] = True
+        self.order.append(b)
+        if self.active:
+            lo, hi = self.bounds[b]
+            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def after_step(self, i: int) -> None:
+        """Every tape closure at position >= i has run."""
+        for b in range(len(self.bounds) - 1, -1, -1):
+            if not self.launched[b] and self.ready_at[b] >= i:
+                self._launch(b)
+
+    def finish(self) -> None:
+        if not self.launched and self.bounds:
+            self.begin({})
+        for b in range(len(self.bounds) - 1, -1, -1):
+            if not self.launched[b]:
+                self._launch(b)
+
+    def wait(self) -> None:
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 def flatten_parameters(groups: List[dict], device=None) -> Tuple[Tensor, List[Tuple[int, int, float]], Dict[int, Tuple[int, int]]]:
     """Move every parameter of the groups into one flat fp32 buffer (group after group) and re-point ``p.data`` at its
     slice.  Every tensor starts on a 256-byte boundary (the kernels use 16-byte vector accesses); the padding is zero
@@ -123,7 +181,7 @@ class Trainer:
 
     def __init__(self, model, *, lr: float = 3e-4, weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8,
                  warmup_steps: int = 0, num_steps: int = 1, accum_iter: int = 1, loss_scaling: bool = True,
-                 bucket_elems: int = 8 << 20):
+                 bucket_elems: int = 8 << 20, overlap_exchange: bool = True, exchange_single_rank: bool = False):
         from . import ops
         from .train import TrainableTail
         self.ops = ops
@@ -136,6 +194,10 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.tail = TrainableTail(model)
         self.grads = {n: self.flat_g[where[id(p)][0]:where[id(p)][1]].view(p.shape) for n, p in self.tail.params.items() if id(p) in where}
+        # gradient exchange: buckets of the flat buffer, launched from the backward tape as their parameters become final
+        self.overlap_exchange = overlap_exchange
+        self.exchange = BucketedExchange(self.flat_g, {n: where[id(p)] for n, p in self.tail.params.items() if id(p) in where},
+                                         bucket_elems, single_rank=exchange_single_rank)
         self.base_lr, self.betas, self.eps = lr, betas, eps
         self.warmup_steps, self.num_steps, self.accum_iter = warmup_steps, num_steps, max(1, accum_iter)
         self.scaler = LossScale(enabled=loss_scaling)
@@ -158,11 +220,18 @@ class Trainer:
         mask = create_text_mask(text, model.sot_token, model.eot_token, model.first_k_tokens) if model.pool_true_text else None
         ids = text.detach().to("cpu", torch.int32).view(-1, text.shape[-1])
         device = self.flat_p.device
+        last_micro = (self.iteration + 1) % self.accum_iter == 0
+        ex = self.exchange if (last_micro and self.exchange.active) else None     # accumulating iterations exchange nothing
+        if ex is not None:
+            ex.begin({})
         loss = self.tail.forward_backward(images.to(device), ids, proprio, gt_actions, mask, self.grads,
-                                          grad_scale=self.scaler.scale / self.accum_iter)
+                                          grad_scale=self.scaler.scale / self.accum_iter,
+                                          **({"exchange": ex} if (ex is not None and self.overlap_exchange) else {}))
         out = {"lr": self.lr, "grad_norm": None, "skipped": False}
-        if (self.iteration + 1) % self.accum_iter == 0:
-            allreduce_flat(self.flat_g, self.bucket_elems)
+        if last_micro:
+            if ex is not None:
+                ex.finish()                                       # whatever the backward pass did not send (everything, without overlap)
+                ex.wait()
             if self._stats_ws is None:
                 self._stats_ws = torch.empty(ops._lib.load().otter_grad_stats_workspace_floats(), dtype=torch.float32, device=device)
             stats = ops.grad_stats(self.flat_g, self._stats_ws)

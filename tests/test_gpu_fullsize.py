@@ -65,6 +65,54 @@ def test_batch64_history12_rollout_at_full_size(dev, default_model):
     assert worst_oracle <= 1e-3 and worst_alone <= 5e-4
 
 
+def test_config5_default_model_window32(dev):
+    """Long-horizon configuration at the REAL model size: default ViT-L/14 + 768-wide 8-layer policy, history window 32,
+    64 concurrent episodes (one GPU's share of 512), 34 steps = 32 filling the K/V cache ([64][32][2304] fp32 per layer)
+    + 2 after the window starts sliding (full-window recompute: 2048 rows through every policy GEMM).  Episodes 0 and 63
+    against single-episode rollouts of the fp32 CPU oracle (1e-3 on actions), episodes 7 and 31 against the same episodes
+    run alone on the device."""
+    from otter_amd.config import ModelConfig, SharedConfig
+    from otter_amd.engine import BatchedRollout
+    from otter_amd.otter import OTTER
+    from otter_amd.params import otter_specs, random_state_dict
+    mc, sc = ModelConfig(), SharedConfig(seq_length=32)
+    sd = random_state_dict(otter_specs(mc, sc), seed=5)
+    assert tuple(sd["pe.pe"].shape) == (1, 32, mc.transformer_dim)
+    model = OTTER(mc, sc)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    d = model.device_model()
+    B, steps = 64, sc.seq_length + 2
+    rng = np.random.default_rng(29)
+    text = GI._tokens(rng, B, (4, 6, 9))
+    tf = d.clip.text_tokens_cached(text)
+    proprio = torch.from_numpy(rng.standard_normal((steps, B, 10)).astype(np.float32))
+    g = torch.Generator().manual_seed(29)
+    batch = BatchedRollout(d, B)
+    dims = R.Dims(seq_length=sc.seq_length)
+    oracles = {e: R.Rollout(sd, dims) for e in (0, 63)}
+    alone = {e: BatchedRollout(d, 1) for e in (7, 31)}
+    worst_oracle = worst_alone = 0.0
+    worst_slide = 0.0
+    for t in range(steps):
+        images = torch.randint(0, 256, (B, 2, 3, 224, 224), dtype=torch.uint8, generator=g)
+        got = batch.step(images.view(B * 2, 3, 224, 224).to(dev), tf, proprio[t].to(dev)).cpu()
+        assert got.shape == (B, sc.action_horizon, mc.action_dim) and torch.isfinite(got).all()
+        for e, ro in oracles.items():
+            ref = ro.step(R.clip_transform(images[e]), text[e], proprio[t, e])
+            err = (got[e] - ref).abs().max().item()
+            worst_oracle = max(worst_oracle, err)
+            if t >= sc.seq_length:
+                worst_slide = max(worst_slide, err)
+        for e, ro in alone.items():
+            a = ro.step(images[e].to(dev), tf[e:e + 1], proprio[t, e:e + 1].to(dev)).cpu()[0]
+            worst_alone = max(worst_alone, (got[e] - a).abs().max().item())
+    assert list(batch.lens_host) == [sc.seq_length] * B
+    print(f"batch 64 x history 32 (default model), {steps} steps: max |action - oracle| = {worst_oracle:.2e} "
+          f"(sliding steps {worst_slide:.2e}), max |batch - alone| = {worst_alone:.2e}")
+    assert worst_oracle <= 1e-3 and worst_alone <= 5e-4
+
+
 def test_training_step_at_one_ranks_full_size(dev, default_model):
     """One data-parallel rank of the global-batch-128 training step: 16 windows x 12 observations x 2 cameras = 384
     ViT-L/14 images.  Actions and loss of window 0 against the fp32 CPU oracle; loss + backward over the whole rank

@@ -215,6 +215,53 @@ def test_batched_rollout_equals_single_episode(dev):
     assert list(batch.lens_host) == [sc.seq_length, 1, sc.seq_length]
 
 
+def test_staggered_episodes_keep_their_kv_cache(dev):
+    """A server whose episodes start and end at different times (window 8, five episodes, a schedule of partial resets):
+    every episode gets, at every step, what the fp32 CPU oracle gives that episode alone; the engine's mode per step is what
+    the per-episode rule says -- cached while the episode's own window is filling (at its own position), recompute once it
+    slides -- so a partial reset never costs the other episodes their K/V cache."""
+    from otter_amd.config import ModelConfig, SharedConfig
+    from otter_amd.engine import BatchedRollout
+    mc = ModelConfig(clip_model="tiny-test", transformer_dim=128, transformer_layers=2, transformer_heads=2, vision_pooling_output_dim=128,
+                     text_pooling_output_dim=64, proprio_hidden_dim=64, proprio_output_dim=32, pooling_heads=4)
+    sc = SharedConfig(image_size=112, seq_length=8, action_horizon=4)
+    model, sd = _model(mc, sc, 31, dev)
+    d = model.device_model()
+    B, steps = 5, 22
+    resets = {2: [1], 3: [3, 4], 5: [0], 9: [2], 13: [1, 4], 17: [0, 1, 2, 3, 4], 19: [2]}      # before the step with that number
+    rng = np.random.default_rng(19)
+    images = torch.from_numpy(rng.integers(0, 256, (steps, B, 2, 3, 112, 112), dtype=np.uint8))
+    proprio = torch.from_numpy(rng.standard_normal((steps, B, 10)).astype(np.float32))
+    text = GI._tokens(rng, B, (4, 7, 9))
+    tf = d.clip.text_tokens_cached(text)
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length)
+    batch = BatchedRollout(d, B)
+    oracles = [R.Rollout(sd, dims) for _ in range(B)]
+    lens = np.zeros(B, dtype=int)
+    worst, modes = 0.0, []
+    for t in range(steps):
+        for e in resets.get(t, []):
+            oracles[e].reset()
+            lens[e] = 0
+        if t in resets:
+            batch.reset(resets[t])
+        got = batch.step(images[t].reshape(B * 2, 3, 112, 112).to(dev), tf, proprio[t].to(dev)).cpu()
+        filling = lens < sc.seq_length
+        want_mode = "cached" if filling.all() else ("recompute" if not filling.any() else "mixed")
+        assert batch.last_mode == want_mode, (t, batch.last_mode, want_mode, lens.tolist())
+        modes.append(batch.last_mode)
+        lens = np.minimum(lens + 1, sc.seq_length)
+        assert list(batch.lens_host) == lens.tolist()
+        for e in range(B):
+            ref = oracles[e].step(R.clip_transform(images[t, e]), text[e], proprio[t, e])
+            worst = max(worst, (got[e] - ref).abs().max().item())
+    print(f"staggered episodes: modes {''.join(m[0] for m in modes)}, max |action - oracle| = {worst:.2e}")
+    assert {"cached", "mixed"} <= set(modes) and worst <= 1e-3
+    with pytest.raises(IndexError):
+        batch.reset([B])
+
+
 def test_openclip_gelu_backbone_text_aware_extraction(dev):
     """OpenCLIP ViT-L/14 variant (GELU instead of QuickGELU; script/open_clip_visualization.py:38-117): per (image, prompt)
     pair, 15 text-token queries plus the pooled text feature as a 16th query, softmax temperature 0.005.

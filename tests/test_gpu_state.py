@@ -118,6 +118,47 @@ def test_history_survives_a_weight_change_and_cache_attribute_assignment(dev):
         model.cached_transformer_input = window[0]
 
 
+def test_two_invalidations_in_a_row_keep_the_running_episode(dev):
+    """Two `invalidate_device_weights()` with no inference call between them (two optimizer steps during an episode): the
+    window carried at the first one survives the second.  And a change of a packed buffer reaches the training-loss path
+    as it reaches inference."""
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    r_images, r_text, r_proprio = GI.rollout_inputs(case)
+    model.reset_cache()
+    for t in range(2):
+        model.forward_inference(r_images[t].to(dev), r_text, r_proprio[t].to(dev))
+    before = model.cached_transformer_input.clone()
+    model.invalidate_device_weights(towers=False)
+    model.invalidate_device_weights(towers=False)
+    assert model.cached_transformer_input is not None
+    torch.testing.assert_close(model.cached_transformer_input, before, rtol=0, atol=0)
+    a2 = model.forward_inference(r_images[2].to(dev), r_text, r_proprio[2].to(dev)).cpu()
+    assert model.cache_size == 3
+    dims = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                  action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length)
+    ro = R.Rollout(sd, dims)
+    for t in range(3):
+        ref = ro.step(R.clip_transform(r_images[t]), r_text, r_proprio[t])
+    assert (a2 - ref).abs().max().item() <= 1e-3
+    model.invalidate_device_weights(keep_history=False)
+    assert model.cached_transformer_input is None
+    # the positional table is a buffer both the inference model and the training tail pack: a change reaches both
+    images, text, proprio, gt = GI.e2e_inputs(case)
+    with torch.no_grad():
+        l0 = model(images.to(dev), text, proprio.to(dev), gt.to(dev)).item()
+        model.pe.pe.mul_(0.0)
+        l1 = model(images.to(dev), text, proprio.to(dev), gt.to(dev)).item()          # the loss path repacks its copy of the table
+        sd2 = dict(sd)
+        sd2["pe.pe"] = torch.zeros_like(sd["pe.pe"])
+        dims_t = R.Dims(first_k_tokens=mc.first_k_tokens, pooling_heads=mc.pooling_heads, transformer_heads=mc.transformer_heads,
+                        action_dim=mc.action_dim, action_horizon=sc.action_horizon, seq_length=sc.seq_length, num_cameras=len(sc.camera_keys),
+                        pool_true_text=mc.pool_true_text, use_mse=sc.mse_loss)
+        ref1 = R.forward(images, text, proprio, sd2, dims_t, gt).item()
+    assert abs(l1 - ref1) <= 1e-3 and abs(l0 - l1) > 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.int16, torch.int32, torch.int64])
 def test_every_integer_image_dtype_is_normalised(dev, dtype):
     """otter/policy/otter.py:367-368 normalises every non-float image tensor, not only uint8."""
@@ -233,3 +274,40 @@ def test_batched_rollout_policy_end_to_end(dev):
         assert got.shape == (n, 7) and np.abs(got[1] - ref).max() <= 1e-4
     pol.start_episodes([1])
     assert pol.queue.counts.cpu().tolist() == [sc.seq_length + 2, 0, sc.seq_length + 2] and pol.rollout.lens_host[1] == 0
+
+
+def test_batched_rollout_policy_follows_weight_updates(dev):
+    """A weight written between two control steps of running episodes reaches the batched policy on its next call (as it
+    reaches OTTER.forward_inference), and the episodes' histories move over to the new weights."""
+    from otter_amd.rollout_server import BatchedRolloutPolicy
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model, sd = _model(mc, sc, case["seed"], dev)
+    n = 2
+    pol = BatchedRolloutPolicy(model, n, 2)
+    rng = np.random.default_rng(14)
+    text = GI._tokens(rng, n, (4, 6))
+    model.reset_cache()
+
+    def call():
+        frames = torch.from_numpy(rng.integers(0, 256, (n * 2, 3, sc.image_size, sc.image_size), dtype=np.uint8)).to(dev)
+        prop = rng.standard_normal((n, 10)).astype(np.float32)
+        chunks = pol.rollout.step(frames, pol.dev.clip.text_tokens_cached(text), torch.from_numpy(prop).to(dev)).cpu()
+        single = model.forward_inference(frames[:2], text[0], torch.from_numpy(prop[0]).to(dev)).cpu()
+        return chunks, single
+
+    for _ in range(2):
+        pol.refresh()
+        chunks, single = call()
+        assert (chunks[0] - single).abs().max().item() <= 2e-4
+    old_dev = pol.dev
+    with torch.no_grad():
+        model.action_head.mlp[2].bias.add_(0.5)
+    pol.refresh()
+    assert pol.dev is not old_dev and list(pol.rollout.lens_host) == [2, 2] and not pol.rollout.kv_ok.any()
+    chunks, single = call()
+    assert model.cache_size == 3 and list(pol.rollout.lens_host) == [3, 3]
+    assert (chunks[0] - single).abs().max().item() <= 2e-4              # new head, old history: same as the single-episode path
+    assert pol.rollout.last_mode == "recompute" and pol.rollout.kv_ok.all()
+    pol.refresh()
+    assert pol.rollout.step.__self__ is pol.rollout                     # unchanged weights: nothing is rebuilt

@@ -192,6 +192,33 @@ def test_real_vocabulary_known_answer_if_available():
     assert tokenize(["a photo of a cat"], tokenizer=tk)[0, :7].tolist() == [49406, 320, 1125, 539, 320, 2368, 49407]
 
 
+def test_non_ascii_prompt_without_ftfy_is_reported(monkeypatch):
+    """clip.tokenize runs ftfy.fix_text first; without ftfy a non-ASCII prompt may tokenise differently from the reference:
+    warned about once per process, an error in strict mode; ASCII prompts are never affected."""
+    import warnings
+    from otter_amd import tokenizer
+    try:
+        import ftfy  # noqa: F401
+        pytest.skip("ftfy is installed: prompts are repaired as the reference repairs them")
+    except ImportError:
+        pass
+    tk = _toy_tokenizer()
+    monkeypatch.setattr(tokenizer, "_warned_unrepaired", False)
+    monkeypatch.delenv("OTTER_TOKENIZER_STRICT", raising=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        tk.encode("pick up the cube")                                  # ASCII: silent
+    with pytest.warns(tokenizer.UnrepairedTextWarning, match="ftfy"):
+        tk.encode("the café table")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        tk.encode("naïve gripper")                                # once per process
+    monkeypatch.setenv("OTTER_TOKENIZER_STRICT", "1")
+    with pytest.raises(RuntimeError, match="ftfy"):
+        tk.encode("the café table")
+    tk.encode("pick up the cube")
+
+
 def test_tokenizer_without_vocabulary_fails_loudly(monkeypatch):
     from otter_amd import tokenizer
     monkeypatch.delenv("OTTER_CLIP_BPE", raising=False)

@@ -95,6 +95,52 @@ def test_gradient_exchange_two_ranks_gloo(tmp_path):
         assert torch.equal(torch.load(tmp_path / f"g{r}.pt"), want)
 
 
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from otter_amd.trainer import BucketedExchange
+        # five parameters in forward order a..e (e is produced after the tape, like the extraction temperatures); buckets of 300
+        where = {"a": (0, 200), "b": (256, 556), "c": (576, 876), "d": (896, 996), "e": (996, 1000)}
+        first_use = {"a": 0, "b": 3, "c": 5, "d": 9}
+        flat = torch.zeros(1000)
+        ex = BucketedExchange(flat, where, bucket_elems=300)
+        assert ex.active and len(ex.bounds) == 4
+        log = []
+        ex.begin(first_use)
+        for i in range(11, -1, -1):                    # the tape replays 12 closures, last to first
+            for n, (lo, hi) in where.items():          # a parameter's gradient is written by the closures at or after its first use
+                if first_use.get(n, -1) == i:
+                    flat[lo:hi] = float(rank + 1) * (1 + "abcde".index(n))
+            before = len(ex.order)
+            ex.after_step(i)
+            log.append((i, list(ex.order[before:])))
+        flat[996:1000] = float(rank + 1) * 5           # "e": after the tape
+        ex.finish()
+        ex.wait()
+        torch.save({"flat": flat, "log": log, "order": ex.order}, os.path.join(out_dir, f"o{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_exchange_overlaps_backward_two_ranks_gloo(tmp_path):
+    """Buckets go out from inside the backward pass, last bucket first, each as soon as every parameter with elements in it
+    is final; the bucket holding a parameter that is produced after the tape waits for finish(); sums are those of one
+    all-reduce over the whole buffer."""
+    mp.spawn(_overlap_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(tmp_path / f"o{r}.pt", weights_only=False) for r in range(2)]
+    # buckets: [0,300) a+b, [300,600) b+c, [600,900) c+d, [900,1000) d+e
+    # bucket 2 (c from step 5, d from step 9) is final after closure 5; bucket 1 (b, c) after closure 3; bucket 0 (a, b) after closure 0;
+    # bucket 3 holds e -> finish()
+    launched = {i: bs for i, bs in res[0]["log"] if bs}
+    assert launched == {5: [2], 3: [1], 0: [0]} and res[0]["order"] == [2, 1, 0, 3]
+    want = torch.zeros(1000)
+    for n, (lo, hi) in {"a": (0, 200), "b": (256, 556), "c": (576, 876), "d": (896, 996), "e": (996, 1000)}.items():
+        want[lo:hi] = 3.0 * (1 + "abcde".index(n))
+    for r in range(2):
+        assert torch.equal(res[r]["flat"], want)
+
+
 def test_bench_launch_wiring_two_ranks(tmp_path):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), with the device step
     stubbed (OTTER_BENCH_STUB=1: gloo, a step sleeps): rank / world parsing, process group, fenced max-over-ranks timing,
@@ -116,9 +162,29 @@ def test_bench_launch_wiring_two_ranks(tmp_path):
     # whole-job rate: both ranks' observations over the SLOWEST rank's time (rank 1 sleeps 4 ms per step, rank 0 2 ms)
     assert out["ms_per_step"] >= 4.0
     assert out["value"] == pytest.approx(2 * 64 * 6 / (out["ms_per_step"] * 6 / 1e3), rel=1e-6)
-    # a world-size mismatch is refused before anything is initialised
-    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
+    # a world-size mismatch (a launcher that started the wrong number of ranks) is refused before anything is initialised
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "needs torchrun" in (bad.stderr + bad.stdout)
+
+
+def test_bench_bare_invocation_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the two ranks itself (a child
+    torch.distributed.run) and relays exactly one JSON line from rank 0 on its stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OTTER_BENCH_STUB"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and "dp2" in out["config"]["parallelism"]
+    assert out["value"] == pytest.approx(2 * 64 * 4 / (out["ms_per_step"] * 4 / 1e3), rel=1e-6)
 
 
 # ---------------------------------------------------------------------------------- data-parallel Trainer on two ranks
@@ -161,7 +227,8 @@ def _oracle_forward_backward(model, dims):
     """Stand-in for TrainableTail.forward_backward: the fp32 CPU oracle differentiated by torch autograd."""
     from oracle import otter_ref as R
 
-    def fb(images, ids, proprio, gt, mask, grads, grad_scale=1.0):
+    def fb(images, ids, proprio, gt, mask, grads, grad_scale=1.0, exchange=None):
+        # (the stand-in reports no progress to `exchange`: Trainer.step then sends every bucket after the pass)
         sd = dict(model.state_dict(keep_vars=True))
         loss = R.forward(images, ids, proprio, sd, dims, gt)
         names = list(grads)

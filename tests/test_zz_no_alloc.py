@@ -88,6 +88,45 @@ def test_static_scratch_gemm_matches_workspace_gemm_twice(dev, dtype):
     torch.testing.assert_close(got.float(), want, rtol=tol, atol=tol)
 
 
+def test_static_scratch_gemm_under_graph_capture_after_init(dev):
+    """After otter_gemm_static_ws_init() (the per-device symbol look-up, outside any capture) the entry point runs under
+    HIP graph capture: a captured split-K product replays to the bits of the eager call, on fresh inputs."""
+    from otter_amd import _lib
+    lib = _lib.load()
+    assert lib.otter_gemm_static_ws_init() == 0 and lib.otter_gemm_static_ws_init() == 0       # idempotent
+    dt = torch.float16
+    m, n, k = 128, 1024, 1024
+    a, wp, bias, res = _problem(dev, dt, m, n, k, 300)
+    a_static, out = a.clone(), _out(dev, dt, m, n)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        _run("otter_gemm_static_ws", dev, dt, a_static, wp, bias, res, m, n, k, 1, out=out)     # once eagerly: LDS opt-ins exist before capture
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(dev)[0]
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        _run("otter_gemm_static_ws", dev, dt, a_static, wp, bias, res, m, n, k, 1, out=out)
+    for seed in (301, 302):
+        a2, _, _, _ = _problem(dev, dt, m, n, k, seed)
+        a_static.copy_(a2)
+        out.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        ws = torch.empty(lib.otter_gemm_workspace_floats(n), dtype=torch.float32, device=dev)
+        ref = _run("otter_gemm_ws", dev, dt, a2, wp, bias, res, m, n, k, 1, ws)
+        assert torch.equal(out, ref)
+    del ws, ref
+    # a stream of another device than the current one is refused (only checkable with two GPUs)
+    if torch.cuda.device_count() > 1:
+        other = torch.cuda.Stream(device=torch.device("cuda", 1))
+        rc = lib.otter_gemm_static_ws(1, ctypes.c_void_p(a.data_ptr()), k, ctypes.c_void_p(wp.data_ptr()), wp.shape[0], None, None, 0, None, None,
+                                      ctypes.c_void_p(out.data_ptr()), n, m, n, k, 0, ctypes.c_void_p(other.cuda_stream))
+        assert rc != 0 and b"belongs to device" in lib.otter_last_error()
+    assert free_before >= 0
+
+
 def test_static_scratch_gemm_rejects_oversize(dev):
     from otter_amd import _lib
     lib = _lib.load()

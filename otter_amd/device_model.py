@@ -79,10 +79,17 @@ class ClipDevice:
     """Frozen CLIP towers as OTTER uses them (``otter.py:177-222``)."""
 
     def __init__(self, sd: Dict[str, Tensor], arch: ClipArch, first_k: int, device, dtype=torch.float16,
-                 prefix: str = "clip_model.", stream_dtype=None):
+                 prefix: str = "clip_model.", stream_dtype=None, text_dtype=None):
+        """``dtype``: 16-bit MFMA operand type of the vision tower (> 99 % of the towers' work).  ``text_dtype``: operand type
+        of the text tower, default fp16 whatever ``dtype`` is: rounding the text tower's tensors to bf16 costs 1.7e-3 of
+        action error on its own (the 15 text tokens steer every softmax of the extraction), the whole vision tower in bf16
+        3.6e-4 (measured class by class: scripts/bf16_error_attribution.py), and the text tower runs once per prompt."""
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError(f"CLIP tower operand dtype must be float16 or bfloat16, got {dtype}")
         self.arch, self.first_k, self.device, self.dtype = arch, first_k, device, dtype
+        self.text_dtype = text_dtype if text_dtype is not None else torch.float16
+        if self.text_dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f"text tower operand dtype must be float16 or bfloat16, got {self.text_dtype}")
         self.stream_dtype = stream_dtype if stream_dtype is not None else (torch.float16 if dtype == torch.float16 else torch.float32)
         if self.stream_dtype not in (torch.float32, dtype):
             raise ValueError(f"residual stream dtype must be float32 or {dtype}, got {self.stream_dtype}")
@@ -108,9 +115,11 @@ class ClipDevice:
         self.tpos = _f32(sd[prefix + "positional_embedding"], device)
         self.tw = self.tok_emb.shape[1]
         self.t_heads = self.tw // 64
-        self.tblocks = _clip_blocks(sd, prefix + "transformer.", device, dtype)
+        self.tblocks = _clip_blocks(sd, prefix + "transformer.", device, self.text_dtype)
+        # the text tower's residual stream: the vision tower's when the operand types agree, else fp32
+        self.text_stream_dtype = self.stream_dtype if self.text_dtype == dtype else torch.float32
         self.ln_final = (_f32(sd[prefix + "ln_final.weight"], device), _f32(sd[prefix + "ln_final.bias"], device))
-        self.w_tproj = ops.pack_weight(sd[prefix + "text_projection"].float().t().contiguous(), dtype, device)
+        self.w_tproj = ops.pack_weight(sd[prefix + "text_projection"].float().t().contiguous(), self.text_dtype, device)
         self._text_cache: Dict[bytes, Tensor] = {}
         # debugging aid (OTTER_DEBUG_STREAM=1): largest |value| of the residual stream after every block, so that a model whose
         # activations approach fp16's range (conversions saturate at +-65504 silently) can be spotted; costs a sync per block
@@ -125,7 +134,7 @@ class ClipDevice:
             if b.fold_ln:
                 qkv = ops.gemm(x, b.wqkv, b.n_qkv, b.bqkv, ln_stats=ops.row_stats(x), ln_colsum=b.cs_qkv)
             else:
-                h = ops.layernorm(x, *b.ln1, out_dtype=self.dtype)
+                h = ops.layernorm(x, *b.ln1, out_dtype=b.dtype)
                 qkv = ops.gemm(h, b.wqkv, b.n_qkv, b.bqkv)
             a = ops.attn_d64(qkv, n_seq, seq_len, heads, causal)
             if stop_after_last_attention and i == len(blocks) - 1:
@@ -135,7 +144,7 @@ class ClipDevice:
             if b.fold_ln:
                 m = ops.gemm(x, b.w_fc, b.n_fc, b.b_fc, act=self.act, ln_stats=ops.row_stats(x), ln_colsum=b.cs_fc)
             else:
-                h = ops.layernorm(x, *b.ln2, out_dtype=self.dtype)
+                h = ops.layernorm(x, *b.ln2, out_dtype=b.dtype)
                 m = ops.gemm(h, b.w_fc, b.n_fc, b.b_fc, act=self.act)
             ops.gemm(m, b.w_proj, b.width, b.b_proj, residual=x, out=x)
             if self.debug_stream:
@@ -178,9 +187,9 @@ class ClipDevice:
         if pooled_row:
             eot = ids.argmax(dim=-1)                                   # end-of-text has the highest id (49407)
             take = max(k, int(eot.max().item()) + 1)
-        x = ops.text_embed(ids, take, self.tok_emb, self.tpos, out_dtype=self.stream_dtype)
+        x = ops.text_embed(ids, take, self.tok_emb, self.tpos, out_dtype=self.text_stream_dtype)
         x = self._run_blocks(x, self.tblocks, b, take, self.t_heads, True, False)
-        h = ops.layernorm(x, *self.ln_final, out_dtype=self.dtype)
+        h = ops.layernorm(x, *self.ln_final, out_dtype=self.text_dtype)
         feats = ops.gemm(h, self.w_tproj, self.embed, None, out_f32=True).view(b, take, self.embed)
         if not pooled_row:
             return feats

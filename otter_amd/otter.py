@@ -61,12 +61,15 @@ class OTTER(nn.Module):
         for spec in otter_specs(mc, sc, self.clip_arch):
             attach(self, spec, None)
 
-        # 16-bit operand type of the CLIP tower MFMAs.  fp16 (default) has 3 more mantissa bits than bf16 at the same
-        # MFMA rate and represents the published CLIP weights exactly; bf16 trades that for fp32's range.
+        # 16-bit operand type of the CLIP vision tower's MFMAs.  fp16 (default) has 3 more mantissa bits than bf16 at the
+        # same MFMA rate and represents the published CLIP weights exactly; bf16 trades that for fp32's range.
         self.clip_compute_dtype = torch.float16
         # Residual stream of the towers: None = fp16 with fp16 operands (the reference's GPU path carries fp16 too), fp32 with
         # bf16 operands; torch.float32 forces the fp32 stream (+2.4 % step time, 4x smaller rounding error in the features).
         self.clip_stream_dtype = None
+        # Operand type of the text tower: None = fp16 whatever the vision tower uses (bf16 rounding of the text tower alone
+        # costs more action error than the tolerance allows; the tower runs once per prompt and is 0.8 % of the work).
+        self.clip_text_dtype = None
         self._dev: Optional[OtterDevice] = None
         self._dev_key = None
         self._clip_dev: Optional[ClipDevice] = None
@@ -147,11 +150,11 @@ class OTTER(nn.Module):
     def clip_device(self) -> ClipDevice:
         """Packed weights of the frozen CLIP towers (rebuilt only when a CLIP tensor or the operand type changes)."""
         device = self._device()
-        key = (self._weights_key(False), self.clip_compute_dtype, self.clip_stream_dtype, device)
+        key = (self._weights_key(False), self.clip_compute_dtype, self.clip_stream_dtype, self.clip_text_dtype, device)
         if self._clip_dev is None or self._clip_key != key:
             sd = {k: v for k, v in self.state_dict().items() if k.startswith("clip_model.")}
             self._clip_dev = ClipDevice(sd, self.clip_arch, self.first_k_tokens, device, self.clip_compute_dtype,
-                                        stream_dtype=self.clip_stream_dtype)
+                                        stream_dtype=self.clip_stream_dtype, text_dtype=self.clip_text_dtype)
             self._clip_key = key
             self._dev = None
         return self._clip_dev

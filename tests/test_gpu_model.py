@@ -122,7 +122,7 @@ def test_default_config_vit_l14_matches_oracle(dev):
     assert worst <= 1e-3
 
 
-@pytest.mark.parametrize("dtype,bound", [(torch.float16, 1e-3), (torch.bfloat16, 2e-3)])
+@pytest.mark.parametrize("dtype,bound", [(torch.float16, 1e-3), (torch.bfloat16, 1e-3)])
 def test_outlier_channel_weights_vit_l14(dev, dtype, bound):
     """Trained CLIP towers carry a few residual-stream channels tens of times larger than the rest, read through small
     LayerNorm gains; N(0, sigma) weights never produce that.  Default configuration with 6 such channels per tower (x60):
@@ -482,13 +482,16 @@ def test_small_batch_encoder_graph_matches_eager(dev, monkeypatch):
 
 
 def test_bf16_towers_and_batch_independence(dev):
-    """bfloat16 operands for the towers (the alternative to the fp16 default): visual tokens still reach cosine 0.9999
-    against the fp32 oracle; actions carry bf16's 8x larger rounding (measured 1.4e-3, bound 2e-3: bf16 operands MISS the path's 1e-3 tolerance, which is why fp16 is the default and the configuration every number is quoted on; the fp16 default is held
-    to 1e-3 above).  Also: an observation's result does not depend on the batch it is computed in (bit for bit)."""
+    """bfloat16 operands for the vision tower (the alternative to the fp16 default; the text tower keeps fp16 operands:
+    its bf16 rounding alone costs 1.7e-3, profiles/r03_bf16_error_attribution.txt): visual tokens reach cosine 0.9999
+    against the fp32 oracle and the actions of four observations stay within the path's 1e-3.  The all-bf16 setting
+    (`clip_text_dtype = bfloat16`) is measured beside it and misses the tolerance -- the reason for the split.
+    Also: an observation's result does not depend on the batch it is computed in."""
     from otter_amd.config import ModelConfig, SharedConfig
     mc, sc = ModelConfig(), SharedConfig()
     model, sd = _model(mc, sc, 0, dev)
     model.clip_compute_dtype = torch.bfloat16
+    assert model.clip_device().text_dtype == torch.float16 and model.clip_device().dtype == torch.bfloat16
     rng = np.random.default_rng(8)
     images = torch.from_numpy(rng.integers(0, 256, (4, 1, 2, 3, 224, 224), dtype=np.uint8))
     text = GI._tokens(rng, 4, (5, 9))
@@ -499,9 +502,12 @@ def test_bf16_towers_and_batch_independence(dev):
     assert min(_cos(pf[c][0].cpu(), ref_pf[c]) for c in range(2)) >= 0.9999
     acts = model(images.to(dev), text, proprio.to(dev)).cpu()
     with torch.no_grad():
-        ref = R.forward(images[:1], text[:1], proprio[:1], sd, R.Dims())
-    err = (acts[:1] - ref).abs().max().item()
-    print(f"bf16 towers: max |action - oracle| = {err:.2e}")
-    assert err <= 2e-3            # measured 1.4e-3; the fp16 default is held to 1e-3 (the path's tolerance) above
+        ref = R.forward(images, text, proprio, sd, R.Dims())
+    err = (acts - ref).abs().max().item()
     alone = model(images[2:3].to(dev), text[2:3], proprio[2:3].to(dev)).cpu()
     torch.testing.assert_close(alone[0], acts[2], rtol=0, atol=5e-4)       # batch independent up to the split-K summation order
+    model.clip_text_dtype = torch.bfloat16                                   # everything in bf16
+    err_all = (model(images.to(dev), text, proprio.to(dev)).cpu() - ref).abs().max().item()
+    print(f"bf16 vision tower + fp16 text tower: max |action - oracle| = {err:.2e}; text tower in bf16 too: {err_all:.2e}")
+    assert err <= 1e-3
+    assert err_all <= 4e-3            # not a supported configuration: recorded, not held to the tolerance

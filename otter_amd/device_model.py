@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from . import ops
+from .torch_ops import kernels as ops      # every kernel launch below is a torch.ops.otter_hip.* call
 from .config import ClipArch
 from .pooling import PoolingWeights
 

@@ -24,7 +24,7 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
-from . import ops
+from .torch_ops import kernels as ops      # every kernel launch below is a torch.ops.otter_hip.* call
 from .device_model import OtterDevice
 
 Tensor = torch.Tensor

@@ -381,9 +381,39 @@ def _readout_check(query: Tensor, final_w: Tensor, final_b: Tensor, kv: Tensor, 
     return ldkv, ldo
 
 
+READOUT_FIELDS = ("q_ln_w", "q_ln_b", "wq_t", "bq", "wo_t", "bo", "ln_w", "ln_b", "fc1_t", "fc1_b", "fc2_t", "fc2_b")   # otter_readout_block
+_BLOCK_ARRAYS: dict = {}
+
+
+def readout_blocks(params):
+    """ctypes array of ``otter_readout_block`` over 12 fp32 device tensors per block (order: ``READOUT_FIELDS``).  Built once
+    per set of addresses and kept together with the tensors, so that the raw pointers in the structs stay valid.
+    A ctypes array passes through unchanged."""
+    if not isinstance(params, (list, tuple)):
+        return params
+    key = tuple(t.data_ptr() for t in params)
+    hit = _BLOCK_ARRAYS.get(key)
+    if hit is None:
+        nf = len(READOUT_FIELDS)
+        if len(params) == 0 or len(params) % nf != 0:
+            raise ValueError(f"readout: {len(params)} block tensors, expected a positive multiple of {nf}")
+        arr = (ReadoutBlock * (len(params) // nf))()
+        for i, t in enumerate(params):
+            _chk(t, torch.float32, "readout.block." + READOUT_FIELDS[i % nf])
+            if not t.is_contiguous():
+                raise ValueError("readout: block parameters must be contiguous")
+            setattr(arr[i // nf], READOUT_FIELDS[i % nf], ctypes.c_void_p(t.data_ptr()))
+        if len(_BLOCK_ARRAYS) > 1024:
+            _BLOCK_ARRAYS.clear()
+        hit = _BLOCK_ARRAYS[key] = (arr, list(params))
+    return hit[0]
+
+
 def readout_pool(blocks, query: Tensor, final_w: Tensor, final_b: Tensor, kv: Tensor, mask: Optional[Tensor], out: Tensor,
                  n_obs: int, nk: int, readouts: int, d: int, heads: int, hidden: int) -> Tensor:
-    """``blocks``: ctypes array of :class:`ReadoutBlock`; kv fp32 (n_obs*nk, >= n_blocks*2d); out fp32 view (n_obs, readouts*d)."""
+    """``blocks``: the blocks' tensors (12 each, ``READOUT_FIELDS`` order) or a ctypes array of :class:`ReadoutBlock`;
+    kv fp32 (n_obs*nk, >= n_blocks*2d); out fp32 view (n_obs, readouts*d)."""
+    blocks = readout_blocks(blocks)
     ldkv, ldo = _readout_check(query, final_w, final_b, kv, mask, out, n_obs, nk, readouts, d)
     _lib.call("otter_readout_pool_fwd", blocks, len(blocks), _ptr(query), _ptr(final_w), _ptr(final_b), _ptr(kv), ldkv, _ptr(mask),
               _ptr(out), ldo, n_obs, nk, readouts, d, heads, hidden, _stream())
@@ -395,6 +425,7 @@ def readout_pool_multi(problems) -> None:
     its order (blocks, query, final_w, final_b, kv, mask, out, n_obs, nk, readouts, d, heads, hidden); at most 4."""
     arr = (_lib.ReadoutProblem * len(problems))()
     for q, (blocks, query, final_w, final_b, kv, mask, out, n_obs, nk, readouts, d, heads, hidden) in zip(arr, problems):
+        blocks = readout_blocks(blocks)
         ldkv, ldo = _readout_check(query, final_w, final_b, kv, mask, out, n_obs, nk, readouts, d)
         q.blocks, q.n_blocks = ctypes.cast(blocks, ctypes.POINTER(_lib.ReadoutBlock)), len(blocks)
         q.query, q.final_ln_w, q.final_ln_b = query.data_ptr(), final_w.data_ptr(), final_b.data_ptr()

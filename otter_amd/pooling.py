@@ -7,13 +7,11 @@ blocks are stacked along N.  The query side runs in the fp32 readout kernel.
 """
 from __future__ import annotations
 
-import ctypes
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 
-from . import ops
-from ._lib import ReadoutBlock
+from .torch_ops import kernels as ops
 
 Tensor = torch.Tensor
 
@@ -34,8 +32,8 @@ class PoolingWeights:
             n += 1
         self.n_blocks = n
         d = self.d
-        ws, bs, self._keep = [], [], []
-        blocks = (ReadoutBlock * n)()
+        ws, bs = [], []
+        self.block_params: List[Tensor] = []              # 12 tensors per block, in the order of otter_readout_block's fields
         for i in range(n):
             p = f"{prefix}blocks.{i}."
             gamma, beta = sd[p + "kv_layer_norm.weight"].float(), sd[p + "kv_layer_norm.bias"].float()
@@ -51,27 +49,25 @@ class PoolingWeights:
                 ln_w=sd[p + "layer_norm.weight"], ln_b=sd[p + "layer_norm.bias"],
                 fc1_t=sd[p + "mlp.fc1.weight"].t(), fc1_b=sd[p + "mlp.fc1.bias"],
                 fc2_t=sd[p + "mlp.fc2.weight"].t(), fc2_b=sd[p + "mlp.fc2.bias"])
-            for name, t in fields.items():
-                t = t.float().contiguous()
-                self._keep.append(t)                      # the struct only holds raw pointers
-                setattr(blocks[i], name, ctypes.c_void_p(t.data_ptr()))
+            assert tuple(fields) == ops.READOUT_FIELDS
+            self.block_params += [t.float().contiguous() for t in fields.values()]
         self.hidden = sd[prefix + "blocks.0.mlp.fc1.weight"].shape[0]
         self.d_in = ws[0].shape[1]
         self.kv_n = 2 * d * n
         self.kv_w = ops.pack_weight(torch.cat(ws, 0), torch.float32)
         self.kv_b = torch.cat(bs, 0).contiguous()
-        self.blocks = blocks
 
     def problem(self, x: Tensor, mask: Optional[Tensor], out: Tensor, n_obs: int, nk: int):
-        """Key / value projection of ``x`` (launched here) and the argument tuple of the readout that consumes it, for
-        :func:`ops.readout_pool` or, with the other poolings of the same encoder call, :func:`ops.readout_pool_multi`."""
+        """Key / value projection of ``x`` (launched here) and the argument tuple of the readout that consumes it
+        (``readout_pool_multi``: the poolings of one encoder call share a launch)."""
         xn = ops.layernorm(x, None, None, out_dtype=torch.float32)
         kv = ops.gemm(xn, self.kv_w, self.kv_n, self.kv_b, out_f32=True)
         m8 = None
         if mask is not None:
             m8 = mask.to(torch.uint8).contiguous()
-        return (self.blocks, self.query, self.final_w, self.final_b, kv, m8, out, n_obs, nk, self.readouts, self.d, self.heads, self.hidden)
+        return (self.block_params, self.query, self.final_w, self.final_b, kv, m8, out, n_obs, nk, self.readouts, self.d, self.heads, self.hidden)
 
     def forward(self, x: Tensor, mask: Optional[Tensor], out: Tensor, n_obs: int, nk: int) -> Tensor:
         """x fp32 (n_obs*nk, D_in); mask bool/uint8 (n_obs, nk) with True = ignore; out fp32 view (n_obs, readouts*d)."""
-        return ops.readout_pool(*self.problem(x, mask, out, n_obs, nk))
+        ops.readout_pool_multi([self.problem(x, mask, out, n_obs, nk)])
+        return out

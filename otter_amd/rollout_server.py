@@ -72,7 +72,7 @@ class DeviceActionQueue:
 
     def step(self, delta_chunks, cur_pose, want_abs: bool = False):
         """delta_chunks fp32 (n, H, 10) on the device, cur_pose fp64 (n, 10) -> (robot (n, 7), executed (n, 10), abs chunks or None)."""
-        from . import ops
+        from .torch_ops import kernels as ops
         return ops.action_step(delta_chunks.contiguous(), cur_pose, self.ring, self.counts, self.horizon, self.receding, self.k, want_abs)
 
 

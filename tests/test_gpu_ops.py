@@ -583,33 +583,150 @@ def test_text_aware_pool_convexity_at_bench_size(dev):
 
 
 def test_torch_custom_ops_match_the_wrappers(dev):
-    """``torch.ops.otter_hip.*`` run the same kernels as :mod:`otter_amd.ops` (bit-identical results)."""
-    import otter_amd.torch_ops  # noqa: F401
+    """Every ``torch.ops.otter_hip.*`` operator runs the same kernel as its :mod:`otter_amd.ops` wrapper (bit-identical
+    results), the mutating forms included."""
+    import otter_amd.torch_ops as T
     from otter_amd import ops
+    from otter_amd.params import pooling_specs, random_state_dict
+    from otter_amd.pooling import PoolingWeights
     ns = torch.ops.otter_hip
+    covered = set()
+
+    def op(name):
+        covered.add(name)
+        return getattr(ns, name)
+
     dt = torch.float16
     a = _randn(91, 300, 128).to(dev).to(dt)
     wp = ops.pack_weight(_randn(92, 248, 128).to(dev) / 11.0, dt)
     bias = _randn(93, 248).to(dev)
     res = _randn(94, 300, 248).to(dev)
-    assert torch.equal(ns.gemm(a, wp, 248, bias, ACTS["quickgelu"], False, None), ops.gemm(a, wp, 248, bias, act=ACTS["quickgelu"]))
+    assert torch.equal(op("gemm")(a, wp, 248, bias, ACTS["quickgelu"], False, None), ops.gemm(a, wp, 248, bias, act=ACTS["quickgelu"]))
     assert torch.equal(ns.gemm(a, wp, 248, bias, 0, False, res), ops.gemm(a, wp, 248, bias, residual=res))
+    wf, bf, cs = ops.fold_layernorm(_randn(92, 248, 128).to(dev) / 11.0, bias, _randn(80, 128).to(dev), _randn(81, 128).to(dev), dt, dev)
+    st = op("row_stats")(a, 1e-5)
+    assert torch.equal(st, ops.row_stats(a))
+    assert torch.equal(ns.gemm(a, wf, 248, bf, 0, False, None, st, cs), ops.gemm(a, wf, 248, bf, ln_stats=st, ln_colsum=cs))
+    big = torch.zeros(300, 264, dtype=dt, device=dev)
+    op("gemm_into")(big[:, 8:256], a, wp, 248, bias, 0, None)                    # a strided view of a wider buffer
+    assert torch.equal(big[:, 8:256], ops.gemm(a, wp, 248, bias)) and torch.all(big[:, :8] == 0) and torch.all(big[:, 256:] == 0)
+    x_res = res.clone()
+    op("gemm_residual_")(x_res, a, wp, 248, bias)
+    assert torch.equal(x_res, ops.gemm(a, wp, 248, bias, residual=res))
     x = _randn(95, 37, 768).to(dev)
     g, b = _randn(96, 768).to(dev), _randn(97, 768).to(dev)
-    assert torch.equal(ns.layernorm(x, g, b, 1e-5, 1), ops.layernorm(x, g, b, out_dtype=dt))
+    assert torch.equal(op("layernorm")(x, g, b, 1e-5, 1), ops.layernorm(x, g, b, out_dtype=dt))
+    imgs = torch.randint(0, 256, (3, 3, 28, 28), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(dev)
+    mean, std = [0.48, 0.45, 0.40], [0.26, 0.26, 0.27]
+    cols = op("im2col_patches")(imgs, 14, 640, mean, std, 1)
+    assert torch.equal(cols, ops.im2col_patches(imgs, 14, 640, mean, std, dt))
+    tok, cls, vpos = _randn(60, 3 * 4, 64).to(dev), _randn(61, 64).to(dev), _randn(62, 5, 64).to(dev)
+    g64, b64 = _randn(63, 64).to(dev), _randn(64, 64).to(dev)
+    assert torch.equal(op("vit_embed_lnpre")(tok, cls, vpos, g64, b64, 3, 4, 1e-5, 1), ops.vit_embed_lnpre(tok, cls, vpos, g64, b64, 3, 4, out_dtype=dt))
+    ids = torch.randint(0, 100, (2, 77), dtype=torch.int32, generator=torch.Generator().manual_seed(4)).to(dev)
+    table, tpos = _randn(65, 100, 64).to(dev), _randn(66, 77, 64).to(dev)
+    assert torch.equal(op("text_embed")(ids, 15, table, tpos, 2), ops.text_embed(ids, 15, table, tpos, out_dtype=torch.float32))
     qkv = _randn(98, 2 * 50, 3 * 128).to(dev).to(dt)
-    assert torch.equal(ns.attn_fwd_d64(qkv, 2, 50, 2, False), ops.attn_d64(qkv, 2, 50, 2, False))
+    assert torch.equal(op("attn_fwd_d64")(qkv, 2, 50, 2, False), ops.attn_d64(qkv, 2, 50, 2, False))
     cache = _randn(99, 3, 12, 3 * 96).to(dev)
-    assert torch.equal(ns.attn_policy(cache, 1, 5, 2), ops.attn_policy(cache, 1, 5, 2))
+    assert torch.equal(op("attn_policy")(cache, 1, 5, 2), ops.attn_policy(cache, 1, 5, 2))
+    # ragged cached step: episodes 2 and 0 at positions 5 and 3 -> the same numbers as the lock-step kernel at those positions
+    lens = torch.tensor([4, 9, 6], dtype=torch.int32, device=dev)
+    idx = torch.tensor([2, 0], dtype=torch.int32, device=dev)
+    fresh = torch.stack([cache[2, 5], cache[0, 3]]).contiguous()
+    c1, c2 = cache.clone(), cache.clone()
+    c1[2, 5], c1[0, 3], c2[2, 5], c2[0, 3] = 0, 0, 0, 0
+    got = op("attn_policy_rows")(fresh, c1, idx, lens, 2)
+    assert torch.equal(got, ops.attn_policy_rows(fresh, c2, idx, lens, 2)) and torch.equal(c1, cache) and torch.equal(c2, cache)
+    assert torch.equal(got[0], ops.attn_policy(cache, 1, 5, 2)[2]) and torch.equal(got[1], ops.attn_policy(cache, 1, 3, 2)[0])
     pos = _randn(100, 49, 512).to(dev)
-    packed = ns.pos_emb_pack(pos, 1)
+    packed = op("pos_emb_pack")(pos, 1)
     assert torch.equal(packed, ops.pos_emb_pack(pos, dt))
     patches = _randn(101, 4, 50, 512).to(dev).to(dt)
     text = _randn(102, 2, 15, 512).to(dev)
     pk = torch.stack([packed, packed])
     temp = torch.full((2,), 0.07, device=dev)
-    assert torch.equal(ns.text_aware_pool(patches, text, pk, temp, 2, 2, 1, 49), ops.text_aware_pool(patches, text, pk, temp, 2, 2, 1, n_patches=49))
-    assert torch.equal(ns.l2norm_rows(x), ops.l2norm_rows(x))
+    assert torch.equal(op("text_aware_pool")(patches, text, pk, temp, 2, 2, 1, 49), ops.text_aware_pool(patches, text, pk, temp, 2, 2, 1, n_patches=49))
+    assert torch.equal(op("l2norm_rows")(x), ops.l2norm_rows(x))
+    # readout: one pooling through the operator against the ctypes-level call
+    sd = random_state_dict(pooling_specs("", 128, 64, 2, 4), seed=5)
+    pw = PoolingWeights({k: v.to(dev) for k, v in sd.items()}, "", 4)
+    xin = _randn(103, 6 * 15, 128).to(dev)
+    o1, o2 = torch.zeros(6, 64, device=dev), torch.zeros(6, 64, device=dev)
+    pr = pw.problem(xin, None, o1, 6, 15)
+    op("readout_pool_multi")(list(pr[0]), [len(pr[0]) // 12], [pr[1]], [pr[2]], [pr[3]], [pr[4]], [None], [o1], [6], [15], [pr[9]], [pr[10]], [pr[11]], [pr[12]])
+    ops.readout_pool(pr[0], pr[1], pr[2], pr[3], pr[4], None, o2, 6, 15, pr[9], pr[10], pr[11], pr[12])
+    assert torch.equal(o1, o2) and float(o1.abs().sum()) > 0
+    xp, wt, bl = _randn(104, 5, 10).to(dev), _randn(105, 10, 256).to(dev), _randn(106, 256).to(dev)
+    assert torch.equal(op("linear_f32")(xp, wt, bl, ACTS["relu"]), ops.linear_f32(xp, wt, bl, ACTS["relu"]))
+    wide = torch.zeros(5, 300, device=dev)
+    op("linear_f32_into")(wide[:, 20:276], xp, wt, bl, 0)
+    assert torch.equal(wide[:, 20:276], ops.linear_f32(xp, wt, bl)) and torch.all(wide[:, :20] == 0)
+    src = _randn(107, 4, 128).to(dev)
+    d1, d2 = torch.zeros(12, 128, device=dev), torch.zeros(12, 128, device=dev)
+    op("repeat_rows_into")(d1, src, 3)
+    assert torch.equal(d1, ops.repeat_rows(src, d2, 3)) and torch.equal(d1, src.repeat_interleave(3, 0))
+    win = _randn(108, 3, 12, 768).to(dev)
+    rows = win.view(36, 768)
+    assert torch.equal(op("convert_rows")(rows, 2, 0, 1, lens, 12, -1, -1), ops.convert_rows(rows, pick=lens, group=12, pick_bias=-1))
+    assert torch.equal(ns.convert_rows(src, 1, 192, 2, None, 1, -1, 0), ops.convert_rows(src, dt, 192, 2))
+    pe = _randn(109, 12, 768).to(dev)
+    assert torch.equal(op("add_pe")(win, pe, 1, 5), ops.add_pe(win, pe, 1, 5))
+    assert torch.equal(op("add_pe_rows")(win, pe, idx, lens), ops.add_pe_rows(win, pe, idx, lens))
+    assert torch.equal(ns.add_pe_rows(win, pe, idx, lens), torch.stack([win[2, 5] + pe[5], win[0, 3] + pe[3]]))
+    newrow = _randn(110, 3, 768).to(dev)
+    w1, w2, l1, l2 = torch.zeros_like(win), torch.zeros_like(win), torch.zeros_like(lens), torch.zeros_like(lens)
+    op("window_append")(win, newrow, w1, lens, l1)
+    ops.window_append(win, newrow, w2, lens, l2)
+    assert torch.equal(w1, w2) and torch.equal(l1, l2) and l1.tolist() == [5, 10, 7]
+    delta = (_randn(111, 4, 12, 10) * 0.2).to(dev)
+    delta[..., 3:9] += torch.tensor([1.0, 0, 0, 0, 1, 0], device=dev)
+    pose = _randn(112, 4, 10).double().to(dev)
+    r1, r2 = torch.zeros(4, 3, 3, 10, dtype=torch.float64, device=dev), torch.zeros(4, 3, 3, 10, dtype=torch.float64, device=dev)
+    n1, n2 = torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+    got = op("action_step")(delta, pose, r1, n1, 3, False, 0.05, True)
+    want = ops.action_step(delta, pose, r2, n2, 3, False, 0.05, True)
+    assert all(torch.equal(u, v) for u, v in zip(got, want)) and torch.equal(r1, r2) and n1.tolist() == [1, 1, 1, 1]
+    assert covered == set(T.OP_NAMES), set(T.OP_NAMES) - covered
+
+
+def test_encoder_traces_into_one_graph_of_custom_operators(dev):
+    """``OtterDevice.encode`` under ``torch.compile(fullgraph=True)``: Dynamo traces the model code with fake tensors (the
+    operators' shape-inference implementations) into ONE graph with no break, every kernel a ``torch.ops.otter_hip`` node;
+    running the traced graph gives the eager launches' bits."""
+    import golden_inputs as GI
+    from otter_amd.otter import OTTER
+    from otter_amd.params import otter_specs, random_state_dict
+    case = GI.E2E_CASES[0]
+    mc, sc = GI.e2e_configs(case)
+    model = OTTER(mc, sc)
+    model.load_state_dict(random_state_dict(otter_specs(mc, sc), seed=case["seed"]), strict=True)
+    d = model.to(dev).eval().device_model()
+    rng = np.random.default_rng(5)
+    n = 3
+    images = torch.from_numpy(rng.integers(0, 256, (n * 2, 3, sc.image_size, sc.image_size), dtype=np.uint8)).to(dev)
+    text = d.clip.text_tokens_cached(GI._tokens(rng, n, (4, 6)))
+    proprio = torch.from_numpy(rng.standard_normal((n, 10)).astype(np.float32)).to(dev)
+    eager = d.encode(images, text, proprio, 1)
+    graphs = []
+
+    def backend(gm, example_inputs):            # no code generation: keep the graph, run it node by node
+        graphs.append(gm)
+        return gm.forward
+
+    torch._dynamo.reset()
+    compiled = torch.compile(d.encode, backend=backend, fullgraph=True)
+    got = compiled(images, text, proprio, 1)
+    assert len(graphs) == 1
+    targets = [str(node.target) for node in graphs[0].graph.nodes if node.op == "call_function"]
+    kernels_in_graph = [t for t in targets if t.startswith("otter_hip.")]
+    names = {t.split(".")[1] for t in kernels_in_graph}
+    print(f"encode(): one FX graph, {len(kernels_in_graph)} otter_hip kernel nodes of {len(targets)} calls; operators {sorted(names)}")
+    assert {"im2col_patches", "gemm", "gemm_residual_", "row_stats", "attn_fwd_d64", "vit_embed_lnpre", "layernorm", "text_aware_pool",
+            "readout_pool_multi", "l2norm_rows", "linear_f32", "linear_f32_into"} <= names
+    assert len(kernels_in_graph) > 20
+    assert torch.equal(got, eager)
+    torch._dynamo.reset()
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])

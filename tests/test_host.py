@@ -442,21 +442,69 @@ def test_resize_arithmetic_is_pil_bicubic_bit_for_bit(h, w, size):
 
 
 def test_torch_custom_ops_are_registered_and_have_no_cpu_implementation():
-    """``torch.ops.otter_hip.*``: schemas, shape inference on meta tensors, and a loud failure on CPU tensors."""
-    import otter_amd.torch_ops  # noqa: F401
+    """``torch.ops.otter_hip.*``: one operator per kernel entry point of the path, shape inference on meta tensors for every one
+    of them, and a loud failure on CPU tensors."""
+    import otter_amd.torch_ops as T
     ns = torch.ops.otter_hip
-    for name in ("gemm", "layernorm", "attn_fwd_d64", "attn_policy", "pos_emb_pack", "text_aware_pool", "l2norm_rows"):
-        assert hasattr(ns, name)
-    meta = lambda *shape, dtype=torch.float16: torch.empty(*shape, dtype=dtype, device="meta")          # noqa: E731
+    assert len(T.OP_NAMES) == 23
+    for name in T.OP_NAMES:
+        assert hasattr(ns, name), name
+    f16, f32, i32, u8, f64 = torch.float16, torch.float32, torch.int32, torch.uint8, torch.float64
+    meta = lambda *shape, dtype=f16: torch.empty(*shape, dtype=dtype, device="meta")          # noqa: E731
     y = ns.gemm(meta(300, 128), meta(256, 128), 256, None, 1, False, None)
-    assert tuple(y.shape) == (300, 256) and y.dtype == torch.float16
-    y = ns.gemm(meta(300, 128), meta(256, 128), 250, None, 0, False, meta(300, 250, dtype=torch.float32))
-    assert tuple(y.shape) == (300, 250) and y.dtype == torch.float32
-    assert ns.layernorm(meta(7, 64, dtype=torch.float32), None, None, 1e-5, 0).dtype == torch.bfloat16
+    assert tuple(y.shape) == (300, 256) and y.dtype == f16
+    y = ns.gemm(meta(300, 128), meta(256, 128), 250, None, 0, False, meta(300, 250, dtype=f32))
+    assert tuple(y.shape) == (300, 250) and y.dtype == f32
+    y = ns.gemm(meta(300, 128), meta(256, 128), 256, meta(256, dtype=f32), 1, False, None, meta(300, 2, dtype=f32), meta(256, dtype=f32))
+    assert tuple(y.shape) == (300, 256) and y.dtype == f16
+    assert ns.gemm_into(meta(300, 256), meta(300, 128), meta(256, 128), 256, None, 0, None) is None
+    assert ns.gemm_residual_(meta(300, 256), meta(300, 128), meta(256, 128), 256, None) is None
+    assert tuple(ns.row_stats(meta(300, 128), 1e-5).shape) == (300, 2)
+    assert ns.layernorm(meta(7, 64, dtype=f32), None, None, 1e-5, 0).dtype == torch.bfloat16
+    y = ns.im2col_patches(meta(4, 3, 224, 224, dtype=u8), 14, 640, [0.5, 0.5, 0.5], [0.2, 0.2, 0.2], 1)
+    assert tuple(y.shape) == (4 * 256, 640) and y.dtype == f16
+    y = ns.vit_embed_lnpre(meta(4 * 256, 1024, dtype=f32), meta(1024, dtype=f32), meta(257, 1024, dtype=f32), meta(1024, dtype=f32), meta(1024, dtype=f32),
+                           4, 256, 1e-5, 1)
+    assert tuple(y.shape) == (4 * 257, 1024) and y.dtype == f16
+    y = ns.text_embed(meta(3, 77, dtype=i32), 15, meta(49408, 768, dtype=f32), meta(77, 768, dtype=f32), 2)
+    assert tuple(y.shape) == (45, 768) and y.dtype == f32
     assert tuple(ns.attn_fwd_d64(meta(2 * 257, 3 * 1024), 2, 257, 16, False).shape) == (514, 1024)
-    assert tuple(ns.attn_policy(meta(3, 12, 3 * 768, dtype=torch.float32), 1, 4, 8).shape) == (3, 768)
-    assert tuple(ns.pos_emb_pack(meta(196, 512, dtype=torch.float32), 1).shape) == (208 * 512,)
-    y = ns.text_aware_pool(meta(4, 257, 768), meta(2, 15, 768, dtype=torch.float32), meta(2, 256 * 768), meta(2, dtype=torch.float32), 2, 2, 1, 256)
-    assert tuple(y.shape) == (2, 2, 15, 768) and y.dtype == torch.float32
+    assert tuple(ns.attn_policy(meta(3, 12, 3 * 768, dtype=f32), 1, 4, 8).shape) == (3, 768)
+    y = ns.attn_policy_rows(meta(2, 3 * 768, dtype=f32), meta(3, 12, 3 * 768, dtype=f32), meta(2, dtype=i32), meta(3, dtype=i32), 8)
+    assert tuple(y.shape) == (2, 768)
+    assert tuple(ns.pos_emb_pack(meta(196, 512, dtype=f32), 1).shape) == (208 * 512,)
+    y = ns.text_aware_pool(meta(4, 257, 768), meta(2, 15, 768, dtype=f32), meta(2, 256 * 768), meta(2, dtype=f32), 2, 2, 1, 256)
+    assert tuple(y.shape) == (2, 2, 15, 768) and y.dtype == f32
+    assert ns.l2norm_rows(meta(5, 768)).dtype == f32
+    blk = [meta(8, dtype=f32) for _ in range(12)]
+    assert ns.readout_pool_multi(blk, [1], [meta(4, 64, dtype=f32)], [meta(64, dtype=f32)], [meta(64, dtype=f32)], [meta(30, 128, dtype=f32)], [None],
+                                 [meta(2, 256, dtype=f32)], [2], [15], [4], [64], [8], [256]) is None
+    assert tuple(ns.linear_f32(meta(5, 10, dtype=f32), meta(10, 256, dtype=f32), None, 3).shape) == (5, 256)
+    assert ns.linear_f32_into(meta(5, 256, dtype=f32), meta(5, 10, dtype=f32), meta(10, 256, dtype=f32), None, 0) is None
+    assert ns.repeat_rows_into(meta(12, 128, dtype=f32), meta(4, 128, dtype=f32), 3) is None
+    assert tuple(ns.convert_rows(meta(24, 768, dtype=f32), 2, 0, 1, meta(2, dtype=i32), 12, -1, -1).shape) == (2, 768)
+    assert tuple(ns.convert_rows(meta(4, 700, dtype=f32), 1, 768, 3, None, 1, -1, 0).shape) == (12, 768)
+    assert tuple(ns.add_pe(meta(3, 12, 768, dtype=f32), meta(12, 768, dtype=f32), 12, 0).shape) == (36, 768)
+    assert tuple(ns.add_pe_rows(meta(3, 12, 768, dtype=f32), meta(12, 768, dtype=f32), meta(2, dtype=i32), meta(3, dtype=i32)).shape) == (2, 768)
+    assert ns.window_append(meta(3, 12, 768, dtype=f32), meta(3, 768, dtype=f32), meta(3, 12, 768, dtype=f32), meta(3, dtype=i32), meta(3, dtype=i32)) is None
+    r, a10, ab = ns.action_step(meta(5, 12, 10, dtype=f32), meta(5, 10, dtype=f64), meta(5, 4, 4, 10, dtype=f64), meta(5, dtype=i32), 4, False, 0.05, True)
+    assert tuple(r.shape) == (5, 7) and tuple(a10.shape) == (5, 10) and tuple(ab.shape) == (5, 12, 10) and r.dtype == f64
     with pytest.raises(NotImplementedError):
         ns.l2norm_rows(torch.randn(3, 8))
+    with pytest.raises(NotImplementedError):
+        ns.gemm(torch.randn(4, 32), torch.randn(256, 32), 8, None, 0, False, None)
+
+
+def test_model_code_launches_kernels_through_the_custom_operators():
+    """device_model / engine / pooling call the kernels through ``torch.ops.otter_hip`` (the `kernels` namespace), not through
+    the ctypes wrappers directly; host-side helpers pass through."""
+    import otter_amd.device_model as dm
+    import otter_amd.engine as eng
+    import otter_amd.pooling as pool
+    from otter_amd import ops as raw
+    from otter_amd.torch_ops import OP_NAMES, kernels
+    assert dm.ops is kernels and eng.ops is kernels and pool.ops is kernels
+    assert kernels.pack_weight is raw.pack_weight and kernels.ACT_GELU == raw.ACT_GELU and kernels.OtterHipError is raw.OtterHipError
+    assert set(kernels._op) == set(OP_NAMES)
+    with pytest.raises(NotImplementedError):                      # a CPU tensor reaches the operator, which has no CPU kernel
+        kernels.l2norm_rows(torch.randn(3, 8))

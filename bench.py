@@ -278,30 +278,69 @@ def measure_kernels(work, steps: int):
     return out
 
 
-def pool_saturated(device, dtype, units: int = 2048, reps: int = 10):
+PEAK_COPY_GBS = 6290.0      # what a float4 device copy reaches on this chip (79 % of the nominal 8 TB/s): the practical streaming ceiling
+POOL_SOURCES = ("otter_amd/csrc/text_aware_pool.hip", "otter_amd/csrc/common.hpp")
+
+
+def pool_sources_sha256() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for rel in POOL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pool_traffic_counters():
+    """(counter bytes per launch of the 2048-unit pooling launch with 16-bit edges, source tag) from the newest
+    profiles/*_pool_traffic.json (FETCH_SIZE and WRITE_SIZE passes of scripts/pool_saturated.py), or (None, reason) when the
+    kernel source changed since."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pool_traffic.json")))
+    if not files:
+        return None, "no profiles/*_pool_traffic.json"
+    try:
+        with open(files[-1]) as fh:
+            pmc = json.load(fh)
+        if pmc.get("kernel_sources_sha256") != pool_sources_sha256():
+            return None, f"profiles/{os.path.basename(files[-1])} is stale (kernel source changed since it was collected)"
+        return pmc["traffic_bytes_per_launch"], f"profiles/{os.path.basename(files[-1])} ({pmc.get('units')} units, 16-bit text in / result out)"
+    except (OSError, KeyError, ValueError) as exc:
+        return None, f"unreadable counter file: {exc}"
+
+
+def pool_saturated(device, dtype, units: int = 2048, reps: int = 10, io16: bool = False):
     """The pooling kernel alone on enough (observation, camera) units to occupy every CU (the step's own launch has
-    128 units: one per workgroup, half the CUs idle): compulsory bytes / launch time, HIP events on the launch stream."""
+    128 units: one per workgroup, half the CUs idle): compulsory bytes / launch time, HIP events on the launch stream.
+    ``io16``: text tokens in and result out in the patches' 16-bit type (the kernel then moves exactly the 439,296
+    algorithmic bytes per unit); otherwise both are fp32 as the step uses them (485,376 bytes moved per unit)."""
     from otter_amd import ops
     p, d, kq, cams = 256, 768, 15, 2
     g = torch.Generator(device=device).manual_seed(5)
     patches = torch.randn(units, p, d, generator=g, device=device).to(dtype)
     text = torch.randn(units // cams, kq, d, generator=g, device=device)
+    if io16:
+        text = text.to(dtype)
+    odt = dtype if io16 else torch.float32
     pos = torch.randn(cams, p, d, generator=g, device=device)
     packed = torch.stack([ops.pos_emb_pack(pos[c].contiguous(), dtype) for c in range(cams)])
     temp = torch.full((cams,), 0.07, device=device)
     for _ in range(2):
-        ops.text_aware_pool(patches, text, packed, temp, units // cams, cams, 1)
+        ops.text_aware_pool(patches, text, packed, temp, units // cams, cams, 1, out_dtype=odt)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.text_aware_pool(patches, text, packed, temp, units // cams, cams, 1)
+        ops.text_aware_pool(patches, text, packed, temp, units // cams, cams, 1, out_dtype=odt)
     e1.record()
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / reps
     gbs = units * POOL_UNIT_BYTES / (us * 1e-6) / 1e9               # the algorithmic 439,296 B per unit
-    moved = units * (p * d * 2 + kq * d * 4 + kq * d * 4) / (us * 1e-6) / 1e9   # what this kernel moves: text in / out are fp32
-    return {"units": units, "avg_launch_us": us, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "bytes_per_unit": POOL_UNIT_BYTES,
-            "moved_gbs": moved, "moved_frac": moved / PEAK_HBM_GBS, "moved_bytes_per_unit": p * d * 2 + kq * d * 8}
+    edge = 2 if io16 else 4
+    moved_unit = p * d * 2 + 2 * kq * d * edge
+    moved = units * moved_unit / (us * 1e-6) / 1e9                  # what this launch moves
+    return {"units": units, "edges": "16-bit text in / result out" if io16 else "fp32 text in / result out", "avg_launch_us": us,
+            "achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "frac_of_copy_ceiling": gbs / PEAK_COPY_GBS, "bytes_per_unit": POOL_UNIT_BYTES,
+            "moved_gbs": moved, "moved_frac": moved / PEAK_HBM_GBS, "moved_bytes_per_unit": moved_unit}
 
 
 def library_gemm_rate(device, dtype, m: int = 32768, reps: int = 10):
@@ -342,8 +381,23 @@ def cpu_baseline(work: Workload, budget_s: float = 15.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 64:
             break
-    return dict(value=n / el, unit="obs/s", cores=cores, kind="port",
-                sample=f"{n} single-episode observations (2 cams 224^2, default config, fp32 torch-CPU oracle, {el:.1f} s)")
+    out = dict(value=n / el, unit="obs/s", cores=cores, kind="port",
+               sample=f"{n} single-episode observations (2 cams 224^2, default config, fp32 torch-CPU oracle, {el:.1f} s)")
+    # a batched point: 8 observations per call through the oracle's full-sequence forward (B = 8, T = 1), a few calls
+    b = 8
+    imgs8 = R.clip_transform(work.images[0][: 2 * b].cpu().view(b, 1, 2, 3, 224, 224))
+    tok8, prop8 = work.tokens[:b], work.proprio[0][:b].cpu().view(b, 1, -1)
+    with torch.no_grad():
+        R.forward(imgs8, tok8, prop8, work.sd, R.Dims())
+        calls, t0 = 0, time.perf_counter()
+        while True:
+            R.forward(imgs8, tok8, prop8, work.sd, R.Dims())
+            calls += 1
+            el8 = time.perf_counter() - t0
+            if el8 >= budget_s / 2 or calls >= 8:
+                break
+    out["batch8"] = dict(value=calls * b / el8, unit="obs/s", sample=f"{calls} calls of {b} observations (B = 8, T = 1) in {el8:.1f} s, same oracle and cores")
+    return out
 
 
 # ------------------------------------------------------------------------------- the other configurations, one block each
@@ -604,12 +658,21 @@ def main():
                                                 "achieved": sg, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sg / PEAK_HBM_GBS,
                                                 "launches": st["launches"], "avg_launch_us": 1e3 * st["total_ms"] / st["launches"]}
             if world == 1 and args.workload == "infer" and not args.no_reference_points:
+                # the kernel alone on a chip-filling launch: as the step calls it (fp32 edges) and moving exactly the
+                # algorithmic bytes (16-bit edges); counter traffic of the latter from the PMC passes under profiles/
                 result["roofline_pool"]["saturated"] = pool_saturated(device, clip_dtype)
+                sat16 = pool_saturated(device, clip_dtype, io16=True)
+                sat16["traffic"], sat16["traffic_source"] = pool_traffic_counters()
+                result["roofline_pool"]["saturated_16bit_edges"] = sat16
+                result["roofline_pool"]["peaks"] = {"hbm_nominal_gbs": PEAK_HBM_GBS, "device_copy_gbs": PEAK_COPY_GBS,
+                                                    "note": "frac is against the nominal 8 TB/s; frac_of_copy_ceiling against the 6.29 TB/s a float4 device copy reaches on this chip"}
         if world == 1 and args.workload == "infer" and not args.no_reference_points:
             el = measure_with_h2d(work, args.steps, max(args.warmup, 1))
             result["value_incl_h2d"] = {"value": work.n * args.steps / el, "unit": "obs/s", "ms_per_step": 1e3 * el / args.steps,
                                         "note": "same steps with the uint8 frames (19.3 MB per step) and proprioception uploaded from pinned host "
-                                                "memory every step on a copy stream, one step ahead, after 12 untimed steps through the same pipeline; never the headline value"}
+                                                "memory every step on a copy stream, one step ahead, after 12 untimed steps through the same pipeline; never the headline value. "
+                                                "Host work in front of the upload (PIL decode / resize, BPE) is not in it: the frames start as uint8 "
+                                                "arrays at the model's resolution and the prompts as token ids"}
         if world == 1 and args.workload == "infer" and not stub and not args.no_other_configs:
             # the other configurations, each a block of its own (never the headline value); a failure in one is reported
             # in its block and does not take the line down

@@ -152,6 +152,13 @@ int otter_attn_policy_rows(const float* fresh, long ldf, float* cache, long ld, 
 int otter_text_aware_pool_fwd(int dtype, const void* patches, long unit_stride, const float* text, const void* pos_packed,
                               const float* temperature, float* out, int n_obs, int cams, int P, int D, int K, int t_rep,
                               void* stream);
+/* The same kernel with 16-bit operands at its edges: io16 bit 0 = `text` holds the patches' 16-bit type instead of fp32
+ * (the text tower's projection can write it directly), bit 1 = `out` is written in that type.  With both a unit moves
+ * 256*768*2 + 2*15*768*2 = 439,296 bytes (the path's compulsory traffic at 16 bits) instead of 485,376.  io16 = 0 is
+ * otter_text_aware_pool_fwd.  The arithmetic inside is unchanged (text rows are normalised in fp32, accumulation in fp32). */
+int otter_text_aware_pool_fwd_io(int dtype, const void* patches, long unit_stride, const void* text, const void* pos_packed,
+                                 const float* temperature, void* out, int n_obs, int cams, int P, int D, int K, int t_rep,
+                                 int io16, void* stream);
 /* pos_emb buffer (sincos_position_embedding, models.py:5-12,19-20) [P][D] fp32 -> 16-bit table in the order the
  * pooling kernel's lanes read it (16-byte coalesced loads); P is rounded up to a multiple of 16 with zero rows. */
 long otter_pos_emb_packed_elems(int P, int D);

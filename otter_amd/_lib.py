@@ -54,6 +54,7 @@ _SIGNATURES = {
     "otter_attn_fwd_d64": [_I, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "otter_attn_policy": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "otter_text_aware_pool_fwd": [_I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "otter_text_aware_pool_fwd_io": [_I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "otter_pos_emb_pack": [_I, _P, _P, _I, _I, _P],
     "otter_readout_pool_fwd": [POINTER(ReadoutBlock), _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "otter_readout_pool_fwd_multi": [POINTER(ReadoutProblem), _I, _P],

@@ -34,10 +34,10 @@ namespace {
 struct TaveArgs {
     const void* patches;        // unit u at patches + u*unit_stride, [P][D] row-major, bf16 or fp16
     long unit_stride;
-    const float* text;          // [n_text][K][D]
+    const void* text;           // [n_text][K][D], fp32 or (TXT16) the patches' 16-bit type
     const void* posF;           // [cams][P/16][4 waves][NDT/2][64 lanes][8]: pos_emb in MFMA-fragment order (otter_pos_emb_pack)
     const float* temperature;   // [cams]
-    float* out;                 // [cams][M][K][D]
+    void* out;                  // [cams][M][K][D], fp32 or (OUT16) the patches' 16-bit type
     int units, cams, P, D, K, t_rep, M;
 };
 
@@ -51,7 +51,9 @@ __device__ __forceinline__ int f_swz(int r) {
 // NW waves per workgroup: each reduces D/NW columns of the similarity product and owns D/NW output columns (NDTW d-tiles
 // of 16).  NST = patch-tile buffers in LDS (prefetch distance NST-1 tiles).  WGS = workgroups the register budget lets
 // share a CU: the waves of co-resident workgroups overlap each other's dependent chains.
-template <typename T, int D, int NW, int NST, int WGS>
+// TXT16 / OUT16: the text tokens arrive / the result leaves in the patches' 16-bit type instead of fp32 (a unit then moves
+// 439,296 bytes instead of 485,376 at P = 256, K = 15, D = 768).
+template <typename T, int D, int NW, int NST, int WGS, bool TXT16, bool OUT16>
 __global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half16<T>::v8 v8;
@@ -104,14 +106,22 @@ __global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
 #pragma unroll
         for (int rr = 0; rr < TRW; ++rr) {               // unrolled: the loads of the wave's rows are in flight together
             const int r = wave * TRW + rr;
-            const float* src = p.text + ((long)b * p.K + r) * D;
+            const long row_off = ((long)b * p.K + r) * D;
             float sq = 0.f;
             f32x4 v[(D / 4 + 63) / 64];
 #pragma unroll
             for (int i = 0; i < (D / 4 + 63) / 64; ++i) {
                 const int idx = i * 64 + lane;
                 v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (idx < D / 4 && r < p.K) v[i] = *(const f32x4*)(src + idx * 4);
+                if (idx < D / 4 && r < p.K) {
+                    if constexpr (TXT16) {
+                        const v4 h = *(const v4*)((const T*)p.text + row_off + idx * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[i][e] = (float)h[e];
+                    } else {
+                        v[i] = *(const f32x4*)((const float*)p.text + row_off + idx * 4);
+                    }
+                }
                 sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
             }
             sq = wave_sum(sq);
@@ -265,19 +275,27 @@ __global__ __launch_bounds__(NW * 64, WGS) void tave_kernel(TaveArgs p) {
     run_sum = rows_sum(run_sum);
     const float inv = 1.0f / run_sum;
     if (li < p.K) {
-        float* dst = p.out + (((long)cam * p.M + m) * p.K + li) * D;
+        const long off = (((long)cam * p.M + m) * p.K + li) * D;
 #pragma unroll
         for (int dt = 0; dt < NDTW; ++dt) {
             const int d0 = (wave * NDTW + dt) * 16;
-            *(f32x4*)(dst + d0 + 4 * g) = o[dt] * inv;
+            const f32x4 r = o[dt] * inv;
+            if constexpr (OUT16) {
+                v4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = Half16<T>::from(r[e]);
+                *(v4*)((T*)p.out + off + d0 + 4 * g) = h;
+            } else {
+                *(f32x4*)((float*)p.out + off + d0 + 4 * g) = r;
+            }
         }
     }
 }
 
-template <typename T, int D, int NW, int NST, int WGS>
+template <typename T, int D, int NW, int NST, int WGS, bool TXT16, bool OUT16>
 int launch_tave_n(const TaveArgs& a, hipStream_t s) {
     constexpr int lds = NST * 16 * D * 2 + NW * (64 * 4 + 16) * 4;   // patch tiles (text image borrows one) + partial-tile exchange
-    auto kern = tave_kernel<T, D, NW, NST, WGS>;
+    auto kern = tave_kernel<T, D, NW, NST, WGS, TXT16, OUT16>;
     if (int rc = otter_reserve_lds((const void*)kern, lds, "otter_text_aware_pool_fwd")) return rc;
     hipLaunchKernelGGL(kern, dim3(a.units), dim3(NW * 64), lds, s, a);
     OTTER_CHECK_LAUNCH("otter_text_aware_pool_fwd");
@@ -285,10 +303,17 @@ int launch_tave_n(const TaveArgs& a, hipStream_t s) {
 }
 
 template <typename T, int D>
-int launch_tave(const TaveArgs& a, hipStream_t s) {
-    // Two buffers of 16 patches: measured against three (same occupancy) and against 8 waves per workgroup, this
-    // is the fastest form at every unit count; the per-tile dependent chain, not the prefetch depth, sets the pace.
-    return launch_tave_n<T, D, 4, 2, 2>(a, s);
+int launch_tave(const TaveArgs& a, int io16, hipStream_t s) {
+    // Two buffers of 16 patches, two workgroups per CU: measured against three buffers (same occupancy), against 8 waves
+    // per workgroup and against a 168-register build that admits a third workgroup (24 registers spill at D = 768:
+    // 273 us against 183 us at 2048 units), this is the fastest form at every unit count; the per-tile dependent chain,
+    // not the prefetch depth or the byte count of the fp32 edges (16-bit edges: same time), sets the pace.
+    switch (io16 & 3) {
+        case 0: return launch_tave_n<T, D, 4, 2, 2, false, false>(a, s);
+        case 1: return launch_tave_n<T, D, 4, 2, 2, true, false>(a, s);
+        case 2: return launch_tave_n<T, D, 4, 2, 2, false, true>(a, s);
+        default: return launch_tave_n<T, D, 4, 2, 2, true, true>(a, s);
+    }
 }
 
 // pos_emb [P][D] fp32 -> 16-bit table in the order tave_kernel's lanes consume it (ndt = D/64):
@@ -311,12 +336,12 @@ __global__ void pos_pack_kernel(const float* pos, T* packed, int P, int D, long 
 }
 
 template <typename T>
-int dispatch_tave(const TaveArgs& a, int D, hipStream_t s) {
+int dispatch_tave(const TaveArgs& a, int D, int io16, hipStream_t s) {
     switch (D) {
-        case 128: return launch_tave<T, 128>(a, s);
-        case 512: return launch_tave<T, 512>(a, s);
-        case 768: return launch_tave<T, 768>(a, s);
-        case 1024: return launch_tave<T, 1024>(a, s);
+        case 128: return launch_tave<T, 128>(a, io16, s);
+        case 512: return launch_tave<T, 512>(a, io16, s);
+        case 768: return launch_tave<T, 768>(a, io16, s);
+        case 1024: return launch_tave<T, 1024>(a, io16, s);
     }
     otter_set_error("otter_text_aware_pool_fwd: D=%d unsupported (128, 512, 768, 1024)", D);
     return OTTER_ERR_UNSUPPORTED_SHAPE;
@@ -324,24 +349,36 @@ int dispatch_tave(const TaveArgs& a, int D, hipStream_t s) {
 
 }  // namespace
 
+static int tave_entry(const char* who, int dtype, const void* patches, long unit_stride, const void* text, const void* pos_packed,
+                      const float* temperature, void* out, int n_obs, int cams, int P, int D, int K, int t_rep, int io16, void* stream) {
+    OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "%s: dtype %d (bf16 or fp16)", who, dtype);
+    OTTER_REQUIRE(patches && text && pos_packed && temperature && out, OTTER_ERR_INVALID_ARGUMENT, "%s: null operand", who);
+    OTTER_REQUIRE((io16 & ~3) == 0, OTTER_ERR_INVALID_ARGUMENT, "%s: io16=%d (bit 0: 16-bit text, bit 1: 16-bit result)", who, io16);
+    if (n_obs == 0) return OTTER_OK;
+    OTTER_REQUIRE(n_obs > 0 && cams > 0 && t_rep > 0, OTTER_ERR_INVALID_ARGUMENT, "%s: bad sizes", who);
+    OTTER_REQUIRE(n_obs % t_rep == 0, OTTER_ERR_INVALID_ARGUMENT, "%s: n_obs=%d not a multiple of t_rep=%d", who, n_obs, t_rep);
+    OTTER_REQUIRE(K >= 1 && K <= 16, OTTER_ERR_UNSUPPORTED_SHAPE, "%s: K=%d text tokens, supports 1..16", who, K);
+    OTTER_REQUIRE(P >= 1 && (long)P * D < (1L << 30), OTTER_ERR_INVALID_ARGUMENT, "%s: P=%d patches", who, P);
+    OTTER_REQUIRE(aligned16(patches) && aligned16(text) && aligned16(pos_packed) && aligned16(out), OTTER_ERR_ALIGNMENT,
+                  "%s: operands must be 16-byte aligned", who);
+    OTTER_REQUIRE((long)n_obs * cams < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "%s: grid too large", who);
+    OTTER_REQUIRE(unit_stride >= (long)P * D && unit_stride % 8 == 0, OTTER_ERR_ALIGNMENT,
+                  "%s: unit_stride=%ld must be >= P*D and a multiple of 8 elements", who, unit_stride);
+    TaveArgs a{patches, unit_stride, text, pos_packed, temperature, out, n_obs * cams, cams, P, D, K, t_rep, n_obs};
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == DT_BF16 ? dispatch_tave<__bf16>(a, D, io16, s) : dispatch_tave<_Float16>(a, D, io16, s);
+}
+
 extern "C" int otter_text_aware_pool_fwd(int dtype, const void* patches, long unit_stride, const float* text, const void* pos_packed,
                                          const float* temperature, float* out, int n_obs, int cams, int P, int D, int K, int t_rep,
                                          void* stream) {
-    OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: dtype %d (bf16 or fp16)", dtype);
-    OTTER_REQUIRE(patches && text && pos_packed && temperature && out, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: null operand");
-    if (n_obs == 0) return OTTER_OK;
-    OTTER_REQUIRE(n_obs > 0 && cams > 0 && t_rep > 0, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: bad sizes");
-    OTTER_REQUIRE(n_obs % t_rep == 0, OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: n_obs=%d not a multiple of t_rep=%d", n_obs, t_rep);
-    OTTER_REQUIRE(K >= 1 && K <= 16, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_fwd: K=%d text tokens, supports 1..16", K);
-    OTTER_REQUIRE(P >= 1 && (long)P * D < (1L << 30), OTTER_ERR_INVALID_ARGUMENT, "otter_text_aware_pool_fwd: P=%d patches", P);
-    OTTER_REQUIRE(aligned16(patches) && aligned16(text) && aligned16(pos_packed) && aligned16(out), OTTER_ERR_ALIGNMENT,
-                  "otter_text_aware_pool_fwd: operands must be 16-byte aligned");
-    OTTER_REQUIRE((long)n_obs * cams < (1L << 31), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_text_aware_pool_fwd: grid too large");
-    OTTER_REQUIRE(unit_stride >= (long)P * D && unit_stride % 8 == 0, OTTER_ERR_ALIGNMENT,
-                  "otter_text_aware_pool_fwd: unit_stride=%ld must be >= P*D and a multiple of 8 elements", unit_stride);
-    TaveArgs a{patches, unit_stride, text, pos_packed, temperature, out, n_obs * cams, cams, P, D, K, t_rep, n_obs};
-    hipStream_t s = (hipStream_t)stream;
-    return dtype == DT_BF16 ? dispatch_tave<__bf16>(a, D, s) : dispatch_tave<_Float16>(a, D, s);
+    return tave_entry("otter_text_aware_pool_fwd", dtype, patches, unit_stride, text, pos_packed, temperature, out, n_obs, cams, P, D, K, t_rep, 0, stream);
+}
+
+extern "C" int otter_text_aware_pool_fwd_io(int dtype, const void* patches, long unit_stride, const void* text, const void* pos_packed,
+                                            const float* temperature, void* out, int n_obs, int cams, int P, int D, int K, int t_rep,
+                                            int io16, void* stream) {
+    return tave_entry("otter_text_aware_pool_fwd_io", dtype, patches, unit_stride, text, pos_packed, temperature, out, n_obs, cams, P, D, K, t_rep, io16, stream);
 }
 
 extern "C" long otter_pos_emb_packed_elems(int P, int D) { return (long)((P + 15) / 16) * 16 * D; }

@@ -327,17 +327,19 @@ def pos_emb_pack(pos: Tensor, dtype=torch.bfloat16) -> Tensor:
 
 
 def text_aware_pool(patches: Tensor, text: Tensor, pos_packed: Tensor, temperature: Tensor, n_obs: int, cams: int, t_rep: int,
-                    n_patches: Optional[int] = None) -> Tensor:
+                    n_patches: Optional[int] = None, out_dtype=torch.float32) -> Tensor:
     """Fused text-aware visual extraction.
 
     patches bf16/fp16: either (n_obs*cams, P, D) contiguous, or (n_obs*cams, L, D) with ``n_patches`` = P < L given,
     in which case the LAST P rows of each unit are used (skips the class token of a ViT output);
-    text fp32 (n_obs/t_rep, K, D); pos_packed (cams, ceil(P/16)*16*D) from :func:`pos_emb_pack` in the patches' dtype;
-    -> fp32 (cams, n_obs, K, D).
+    text (n_obs/t_rep, K, D) fp32 or the patches' dtype; pos_packed (cams, ceil(P/16)*16*D) from :func:`pos_emb_pack` in
+    the patches' dtype; -> (cams, n_obs, K, D) in ``out_dtype`` (fp32 or the patches' dtype).
     """
     dt = _dt(patches.dtype, "tave.patches", False)
     _chk(patches, patches.dtype, "tave.patches", 3)
-    _chk(text, torch.float32, "tave.text", 3)
+    if text.dtype not in (torch.float32, patches.dtype) or out_dtype not in (torch.float32, patches.dtype):
+        raise TypeError(f"tave: text {text.dtype} / out {out_dtype} must be float32 or {patches.dtype}")
+    _chk(text, text.dtype, "tave.text", 3)
     _chk(pos_packed, patches.dtype, "tave.pos_packed", 2)
     _chk(temperature, torch.float32, "tave.temperature", 1)
     units, rows, d = patches.shape
@@ -350,12 +352,17 @@ def text_aware_pool(patches: Tensor, text: Tensor, pos_packed: Tensor, temperatu
     for t in (patches, text, pos_packed, temperature):
         if not t.is_contiguous():
             raise ValueError("tave: operands must be contiguous")
-    out = torch.empty(cams, n_obs, k, d, dtype=torch.float32, device=patches.device)
+    out = torch.empty(cams, n_obs, k, d, dtype=out_dtype, device=patches.device)
     if n_obs == 0:
         return out
     base = ctypes.c_void_p(patches.data_ptr() + (rows - p) * d * 2)
-    _lib.call("otter_text_aware_pool_fwd", dt, base, rows * d, _ptr(text), _ptr(pos_packed), _ptr(temperature), _ptr(out),
-              n_obs, cams, p, d, k, t_rep, _stream())
+    io16 = int(text.dtype != torch.float32) | (int(out_dtype != torch.float32) << 1)
+    if io16 == 0:
+        _lib.call("otter_text_aware_pool_fwd", dt, base, rows * d, _ptr(text), _ptr(pos_packed), _ptr(temperature), _ptr(out),
+                  n_obs, cams, p, d, k, t_rep, _stream())
+    else:
+        _lib.call("otter_text_aware_pool_fwd_io", dt, base, rows * d, _ptr(text), _ptr(pos_packed), _ptr(temperature), _ptr(out),
+                  n_obs, cams, p, d, k, t_rep, io16, _stream())
     return out
 
 

@@ -417,6 +417,31 @@ def test_text_aware_pool(dev, n_obs, cams, P, D, K, t_rep, temperature, dtype):
         torch.testing.assert_close(out[c], ref, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_text_aware_pool_16bit_edges(dev, dtype):
+    """Text tokens in / result out in the patches' 16-bit type: against the fp32-edged launch of the same kernel.  16-bit text
+    alone changes the result by what rounding the text rows costs; a 16-bit result is the fp32 result rounded once."""
+    from otter_amd import ops
+    dt = DTYPES[dtype]
+    n_obs, cams, P, D, K = 5, 2, 256, 768, 15
+    g = torch.Generator().manual_seed(17)
+    patches = torch.randn(n_obs * cams, P + 1, D, generator=g).to(dev).to(dt)
+    text = torch.randn(n_obs, K, D, generator=g).to(dev)
+    pos = torch.stack([ops.pos_emb_pack(torch.randn(P, D, generator=g).to(dev), dt) for _ in range(cams)])
+    temp = torch.tensor([0.07, 0.1], device=dev)
+    base = ops.text_aware_pool(patches, text, pos, temp, n_obs, cams, 1, n_patches=P)
+    out16 = ops.text_aware_pool(patches, text, pos, temp, n_obs, cams, 1, n_patches=P, out_dtype=dt)
+    assert out16.dtype == dt and torch.equal(out16, base.to(dt))              # the same accumulators, rounded once
+    t16 = text.to(dt)
+    both = ops.text_aware_pool(patches, t16, pos, temp, n_obs, cams, 1, n_patches=P, out_dtype=dt)
+    ref16 = ops.text_aware_pool(patches, t16.float(), pos, temp, n_obs, cams, 1, n_patches=P)      # fp32 edges fed the rounded text
+    assert torch.equal(both, ref16.to(dt))
+    tol = 3e-2 if dtype == "bf16" else 4e-3
+    torch.testing.assert_close(both.float(), base, rtol=tol, atol=tol)
+    with pytest.raises(TypeError):
+        ops.text_aware_pool(patches, text.double(), pos, temp, n_obs, cams, 1, n_patches=P)
+
+
 @pytest.mark.parametrize("case_name", ["vision_nomask", "text_mask", "small"])
 def test_readout_pool(dev, case_name):
     import golden_inputs as GI

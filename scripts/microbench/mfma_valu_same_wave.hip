@@ -1,0 +1,67 @@
+// How many independent vector instructions fit in the shadow of one MFMA (same wave), one or two waves per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+template <int SHAPE, int KF, int KE>    // per MFMA: KF fma + KE exp (independent chains)
+__global__ __launch_bounds__(512) void k(int iters, long long* out, float* sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    h8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(lane * 0.001f + i); b[i] = (_Float16)(i * 0.01f); }
+    float x[8], y[8];
+    for (int i = 0; i < 8; ++i) { x[i] = lane * 0.01f + i; y[i] = -lane * 0.01f - i; }
+    float acc_out = 0.f;
+    long long t0, t1;
+    constexpr int NM = SHAPE == 0 ? 8 : 4;
+    f4 c4[8]; f16v c16[4];
+    for (int i = 0; i < 8; ++i) c4[i] = (f4){0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) c16[i][j] = 0.f;
+    __syncthreads();
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            if constexpr (SHAPE == 0) c4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c4[i], 0, 0, 0);
+            else c16[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c16[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < KF; ++j) x[(i * KF + j) & 7] = __builtin_fmaf(x[(i * KF + j) & 7], 0.999f, 0.001f);
+#pragma unroll
+            for (int j = 0; j < KE; ++j) y[(i * KE + j) & 7] = __builtin_amdgcn_exp2f(y[(i * KE + j) & 7]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 8; ++i) acc_out += c4[i][0] + x[i] + y[i];
+    for (int i = 0; i < 4; ++i) acc_out += c16[i][0];
+    if (lane == 0) out[wave] = t1 - t0;
+    if (acc_out == 12345.678f) sink[0] = acc_out;
+}
+
+template <int SHAPE, int KF, int KE>
+void run(long long* d_out, float* sink) {
+    const int iters = 2000;
+    long long h[8];
+    double r[2];
+    for (int nw = 0; nw < 2; ++nw) {
+        const int threads = nw == 0 ? 256 : 512;
+        hipLaunchKernelGGL((k<SHAPE, KF, KE>), dim3(1), dim3(threads), 0, 0, iters, d_out, sink);
+        hipLaunchKernelGGL((k<SHAPE, KF, KE>), dim3(1), dim3(threads), 0, 0, iters, d_out, sink);
+        hipDeviceSynchronize();
+        hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost);
+        r[nw] = (double)h[0] / iters / (SHAPE == 0 ? 8 : 4);
+    }
+    printf("%s  per MFMA: %d fma + %d exp : 1 wave/SIMD %.1f cycles per MFMA, 2 waves/SIMD %.1f (per wave)\n", SHAPE == 0 ? "16x16x32" : "32x32x16", KF, KE, r[0], r[1]);
+}
+
+int main() {
+    long long* d_out; float* sink;
+    hipMalloc(&d_out, 64); hipMalloc(&sink, 4);
+    run<0, 0, 0>(d_out, sink); run<0, 1, 0>(d_out, sink); run<0, 2, 0>(d_out, sink); run<0, 3, 0>(d_out, sink); run<0, 4, 0>(d_out, sink); run<0, 6, 0>(d_out, sink);
+    run<0, 0, 1>(d_out, sink); run<0, 0, 2>(d_out, sink); run<0, 2, 1>(d_out, sink); run<0, 3, 1>(d_out, sink);
+    run<1, 0, 0>(d_out, sink); run<1, 2, 0>(d_out, sink); run<1, 4, 0>(d_out, sink); run<1, 6, 0>(d_out, sink); run<1, 7, 0>(d_out, sink); run<1, 8, 0>(d_out, sink); run<1, 10, 0>(d_out, sink);
+    run<1, 0, 1>(d_out, sink); run<1, 0, 2>(d_out, sink); run<1, 0, 3>(d_out, sink); run<1, 4, 1>(d_out, sink); run<1, 4, 2>(d_out, sink); run<1, 6, 2>(d_out, sink); run<1, 3, 3>(d_out, sink);
+    return 0;
+}

@@ -36,15 +36,15 @@ __global__ __launch_bounds__(512) void k(int iters, long long* out, float* sink)
     t1 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < 8; ++i) acc_out += c4[i][0] + x[i] + y[i];
     for (int i = 0; i < 4; ++i) acc_out += c16[i][0];
-    if (lane == 0) out[wave] = t1 - t0;
+    if (lane == 0) { out[wave] = t1 - t0; out[8 + wave] = t0; out[16 + wave] = t1; }
     if (acc_out == 12345.678f) sink[0] = acc_out;
 }
 
 template <int SHAPE, int KF, int KE>
 void run(long long* d_out, float* sink) {
     const int iters = 2000;
-    long long h[8];
-    double r[2];
+    long long h[24];
+    double r[2], span[2] = {0, 0}, w4[2] = {0, 0};
     for (int nw = 0; nw < 2; ++nw) {
         const int threads = nw == 0 ? 256 : 512;
         hipLaunchKernelGGL((k<SHAPE, KF, KE>), dim3(1), dim3(threads), 0, 0, iters, d_out, sink);
@@ -52,13 +52,14 @@ void run(long long* d_out, float* sink) {
         hipDeviceSynchronize();
         hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost);
         r[nw] = (double)h[0] / iters / (SHAPE == 0 ? 8 : 4);
+        if (nw == 1) { w4[1] = (double)h[4] / iters / (SHAPE == 0 ? 8 : 4); long long a = h[8] < h[12] ? h[8] : h[12], b = h[16] > h[20] ? h[16] : h[20]; span[1] = (double)(b - a) / iters / (SHAPE == 0 ? 8 : 4); }
     }
-    printf("%s  per MFMA: %d fma + %d exp : 1 wave/SIMD %.1f cycles per MFMA, 2 waves/SIMD %.1f (per wave)\n", SHAPE == 0 ? "16x16x32" : "32x32x16", KF, KE, r[0], r[1]);
+    printf("%s  per MFMA: %d fma + %d exp : 1 wave/SIMD %.1f cycles per MFMA; 2 waves/SIMD: wave 0 %.1f, wave 4 %.1f, both done after %.1f per MFMA-pair\n", SHAPE == 0 ? "16x16x32" : "32x32x16", KF, KE, r[0], r[1], w4[1], span[1]);
 }
 
 int main() {
     long long* d_out; float* sink;
-    hipMalloc(&d_out, 64); hipMalloc(&sink, 4);
+    hipMalloc(&d_out, 256); hipMalloc(&sink, 4);
     run<0, 0, 0>(d_out, sink); run<0, 1, 0>(d_out, sink); run<0, 2, 0>(d_out, sink); run<0, 3, 0>(d_out, sink); run<0, 4, 0>(d_out, sink); run<0, 6, 0>(d_out, sink);
     run<0, 0, 1>(d_out, sink); run<0, 0, 2>(d_out, sink); run<0, 2, 1>(d_out, sink); run<0, 3, 1>(d_out, sink);
     run<1, 0, 0>(d_out, sink); run<1, 2, 0>(d_out, sink); run<1, 4, 0>(d_out, sink); run<1, 6, 0>(d_out, sink); run<1, 7, 0>(d_out, sink); run<1, 8, 0>(d_out, sink); run<1, 10, 0>(d_out, sink);

@@ -104,12 +104,30 @@ class BucketedExchange:
     end of the buffer go first.  :meth:`finish` launches what is left (parameters whose gradient is produced after the
     tape, parameters the pass never touched), :meth:`wait` makes the current stream wait for all of them.
 
+    ``algo``: "all_reduce" (the library picks ring or tree), or "reduce_scatter_all_gather": each bucket as an explicit
+    reduce-scatter (every rank ends up with the sum of its 1/world slice) followed by an all-gather of the slices.  On a
+    point-to-point xGMI mesh both halves are single-hop exchanges between every pair of GPUs, where a ring pushes the whole
+    bucket 2 (world - 1) times through one link after the other.  The two give the same sums up to the order of addition.
+
     Without a process group (or on one rank, unless ``single_rank`` asks for the collectives anyway: a rehearsal of the
     RCCL path on a one-GPU box) every method is a no-op."""
 
-    def __init__(self, flat: Tensor, where: Dict[str, Tuple[int, int]], bucket_elems: int = 8 << 20, single_rank: bool = False):
+    ALGOS = ("all_reduce", "reduce_scatter_all_gather")
+
+    def __init__(self, flat: Tensor, where: Dict[str, Tuple[int, int]], bucket_elems: int = 8 << 20, single_rank: bool = False,
+                 algo: str = "all_reduce"):
+        if algo not in self.ALGOS:
+            raise ValueError(f"exchange algorithm {algo!r}: one of {self.ALGOS}")
         self.flat = flat
+        self.algo = algo
         self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank)
+        self.world = dist.get_world_size() if self.active else 1
+        self.rank = dist.get_rank() if self.active else 0
+        # collectives of one NCCL / RCCL communicator run in issue order on its stream, so the all-gather can be queued right
+        # behind its reduce-scatter; other backends run queued work on a thread pool: there the all-gathers wait for wait()
+        self._chained = self.active and dist.get_backend() == "nccl"
+        self._shards: Dict[int, Tensor] = {}
+        self._pending_gather: List[int] = []
         self.bounds = bucket_bounds(flat.numel(), bucket_elems)
         # names with elements in each bucket (a parameter may straddle two buckets)
         self.members: List[List[str]] = [[n for n, (a, b) in where.items() if a < hi and b > lo] for lo, hi in self.bounds]
@@ -123,14 +141,25 @@ class BucketedExchange:
         final before :meth:`finish`."""
         self.ready_at = [min((first_use.get(n, -1) for n in names), default=-1) for names in self.members]
         self.launched = [False] * len(self.bounds)
-        self.works, self.order = [], []
+        self.works, self.order, self._pending_gather = [], [], []
 
     def _launch(self, b: int) -> None:
         self.launched[b] = True
         self.order.append(b)
-        if self.active:
-            lo, hi = self.bounds[b]
+        if not self.active:
+            return
+        lo, hi = self.bounds[b]
+        n = hi - lo
+        if self.algo == "all_reduce" or n % self.world:
             self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            return
+        if b not in self._shards:
+            self._shards[b] = torch.empty(n // self.world, dtype=self.flat.dtype, device=self.flat.device)
+        self.works.append(dist.reduce_scatter_tensor(self._shards[b], self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        if self._chained:
+            self.works.append(dist.all_gather_into_tensor(self.flat[lo:hi], self._shards[b], async_op=True))
+        else:
+            self._pending_gather.append(b)
 
     def after_step(self, i: int) -> None:
         """Every tape closure at position >= i has run."""
@@ -149,6 +178,12 @@ class BucketedExchange:
         for w in self.works:
             w.wait()
         self.works = []
+        if self._pending_gather:
+            works = [dist.all_gather_into_tensor(self.flat[self.bounds[b][0]:self.bounds[b][1]], self._shards[b], async_op=True)
+                     for b in self._pending_gather]
+            self._pending_gather = []
+            for w in works:
+                w.wait()
 
 
 def flatten_parameters(groups: List[dict], device=None) -> Tuple[Tensor, List[Tuple[int, int, float]], Dict[int, Tuple[int, int]]]:
@@ -181,7 +216,8 @@ class Trainer:
 
     def __init__(self, model, *, lr: float = 3e-4, weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8,
                  warmup_steps: int = 0, num_steps: int = 1, accum_iter: int = 1, loss_scaling: bool = True,
-                 bucket_elems: int = 8 << 20, overlap_exchange: bool = True, exchange_single_rank: bool = False):
+                 bucket_elems: int = 8 << 20, overlap_exchange: bool = True, exchange_single_rank: bool = False,
+                 exchange_algo: str = "all_reduce"):
         from . import ops
         from .train import TrainableTail
         self.ops = ops
@@ -197,7 +233,7 @@ class Trainer:
         # gradient exchange: buckets of the flat buffer, launched from the backward tape as their parameters become final
         self.overlap_exchange = overlap_exchange
         self.exchange = BucketedExchange(self.flat_g, {n: where[id(p)] for n, p in self.tail.params.items() if id(p) in where},
-                                         bucket_elems, single_rank=exchange_single_rank)
+                                         bucket_elems, single_rank=exchange_single_rank, algo=exchange_algo)
         self.base_lr, self.betas, self.eps = lr, betas, eps
         self.warmup_steps, self.num_steps, self.accum_iter = warmup_steps, num_steps, max(1, accum_iter)
         self.scaler = LossScale(enabled=loss_scaling)

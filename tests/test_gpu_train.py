@@ -371,10 +371,11 @@ def test_trainer_step_through_rccl_on_one_rank(dev):
     mc, sc = GI.e2e_configs(case)
     images, text, proprio, gt = GI.e2e_inputs(case)
 
-    def run(with_group: bool):
+    def run(with_group: bool, algo: str = "all_reduce"):
         model, _ = _model(mc, sc, case["seed"], dev)
         model.train()
-        tr = Trainer(model, lr=3e-4, weight_decay=0.01, warmup_steps=0, num_steps=100, bucket_elems=50_000, exchange_single_rank=with_group)
+        tr = Trainer(model, lr=3e-4, weight_decay=0.01, warmup_steps=0, num_steps=100, bucket_elems=50_000, exchange_single_rank=with_group,
+                     exchange_algo=algo)
         assert tr.exchange.active == with_group and len(tr.exchange.bounds) > 3
         logs = [tr.step(images.to(dev), text, proprio.to(dev), gt.to(dev)) for _ in range(2)]
         torch.cuda.synchronize()
@@ -398,6 +399,14 @@ def test_trainer_step_through_rccl_on_one_rank(dev):
         torch.cuda.synchronize()
         assert torch.equal(flat.cpu(), torch.arange(1000, dtype=torch.float32)) and ex.order == [3, 2, 1, 0]
         grouped, logs1, order = run(True)
+        # the same exchange as explicit reduce-scatter + all-gather pairs (queued back to back on RCCL's stream)
+        flat2 = torch.arange(1000, dtype=torch.float32, device=dev)
+        ex2 = BucketedExchange(flat2, {"all": (0, 1000)}, bucket_elems=300, single_rank=True, algo="reduce_scatter_all_gather")
+        ex2.finish()
+        ex2.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(flat2.cpu(), torch.arange(1000, dtype=torch.float32))
+        scattered, logs2, order2 = run(True, "reduce_scatter_all_gather")
     finally:
         dist.destroy_process_group()
         for k, v in saved.items():
@@ -405,7 +414,8 @@ def test_trainer_step_through_rccl_on_one_rank(dev):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    assert torch.equal(plain, grouped)
+    assert torch.equal(plain, grouped) and torch.equal(plain, scattered) and order2 == order
+    assert [l["loss"] for l in logs0] == [l["loss"] for l in logs2]
     assert [l["loss"] for l in logs0] == [l["loss"] for l in logs1] and [l["grad_norm"] for l in logs0] == [l["grad_norm"] for l in logs1]
     # buckets left in the order the backward pass finished them: the end of the flat buffer (action head, last policy
     # layers) first, and more than one of them BEFORE the pass was over (the last launch is finish()'s)

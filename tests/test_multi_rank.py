@@ -95,7 +95,7 @@ def test_gradient_exchange_two_ranks_gloo(tmp_path):
         assert torch.equal(torch.load(tmp_path / f"g{r}.pt"), want)
 
 
-def _overlap_worker(rank, world, port, out_dir):
+def _overlap_worker(rank, world, port, out_dir, algo):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -104,7 +104,7 @@ def _overlap_worker(rank, world, port, out_dir):
         where = {"a": (0, 200), "b": (256, 556), "c": (576, 876), "d": (896, 996), "e": (996, 1000)}
         first_use = {"a": 0, "b": 3, "c": 5, "d": 9}
         flat = torch.zeros(1000)
-        ex = BucketedExchange(flat, where, bucket_elems=300)
+        ex = BucketedExchange(flat, where, bucket_elems=300, algo=algo)
         assert ex.active and len(ex.bounds) == 4
         log = []
         ex.begin(first_use)
@@ -123,11 +123,12 @@ def _overlap_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_bucketed_exchange_overlaps_backward_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("algo", ["all_reduce", "reduce_scatter_all_gather"])
+def test_bucketed_exchange_overlaps_backward_two_ranks_gloo(tmp_path, algo):
     """Buckets go out from inside the backward pass, last bucket first, each as soon as every parameter with elements in it
     is final; the bucket holding a parameter that is produced after the tape waits for finish(); sums are those of one
-    all-reduce over the whole buffer."""
-    mp.spawn(_overlap_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    all-reduce over the whole buffer -- as all-reduces and as explicit reduce-scatter + all-gather pairs."""
+    mp.spawn(_overlap_worker, args=(2, _free_port(), str(tmp_path), algo), nprocs=2, join=True)
     res = [torch.load(tmp_path / f"o{r}.pt", weights_only=False) for r in range(2)]
     # buckets: [0,300) a+b, [300,600) b+c, [600,900) c+d, [900,1000) d+e
     # bucket 2 (c from step 5, d from step 9) is final after closure 5; bucket 1 (b, c) after closure 3; bucket 0 (a, b) after closure 0;

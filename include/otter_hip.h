@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define OTTER_HIP_ABI_VERSION 13
+#define OTTER_HIP_ABI_VERSION 14
 
 /* element type codes */
 #define OTTER_DT_BF16 0
@@ -86,6 +86,14 @@ int otter_gemm_static_ws_init(void);
 int otter_gemm_static_ws(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, const void* residual,
                          long ldr, const float* row_stats, const float* col_sum, void* C, long ldc, int M, int N, int K,
                          int epilogue, void* stream);
+/* The residual product of a CLIP resblock together with the statistics of the LayerNorm that reads its result
+ * (`x = x + attn(ln_1(x))` followed by ln_2, `x = x + mlp(ln_2(x))` followed by the next block's ln_1: the resblocks reached
+ * from otter.py:189-190): x[M][N] += A[M][K] W[N][K]^T + bias in place on the 16-bit residual stream, then
+ * stats[r] = (mean, rstd) of the updated row r.  Bit for bit otter_gemm_ws with OTTER_EPI_RESIDUAL followed by
+ * otter_row_stats; when the < 256 remainder rows are multiplied split-K their second pass shares one launch with the
+ * statistics of all rows.  N <= 1024, N % 8 == 0; workspace as otter_gemm_ws (NULL: two plain launches). */
+int otter_gemm_residual_stats(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, void* x, long ldx,
+                              int M, int N, int K, float* stats, float eps, float* workspace, long workspace_floats, void* stream);
 /* stats[r] = (mean, 1/sqrt(var + eps)) of row r (two-pass, fp32), x fp32 or 16-bit. */
 int otter_row_stats(const void* x, int in_dtype, long ldx, float* stats, int rows, int width, float eps, void* stream);
 

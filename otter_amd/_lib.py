@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_HIP_LIB") or os.path.join(_HERE, "libotter_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "otter_gemm_static_ws": [_I, _P, _L, _P, _I, _P, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "otter_gemm_ln": [_I, _P, _L, _P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "otter_row_stats": [_P, _I, _L, _P, _I, _I, _F, _P],
+    "otter_gemm_residual_stats": [_I, _P, _L, _P, _I, _P, _P, _L, _I, _I, _I, _P, _F, _P, _L, _P],
     "otter_layernorm": [_P, _I, _L, _P, _P, _P, _L, _I, _I, _F, _I, _P],
     "otter_vit_embed_lnpre": [_P, _L, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P],
     "otter_text_embed": [_P, _I, _I, _P, _I, _P, _P, _I, _L, _I, _I, _P],

@@ -131,6 +131,28 @@ __device__ __forceinline__ float rows_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// (mean, 1 / sqrt(var + eps)) of one row of `width` 16-bit values held 8 per lane and vector: vector i of lane l is elements
+// (i * 64 + l) * 8 .. + 7 of the row (zero beyond the width).  Two-pass on the registers; every lane gets the result.
+// Shared by the row-statistics kernel and by the split-K reduce that finishes a residual row and takes its statistics.
+template <typename T>
+__device__ __forceinline__ f32x2 row_mean_rstd_16(const typename Half16<T>::v8 (&v)[2], int lane, int nvec, float inv_w, float eps) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+    const float mean = wave_sum(sum) * inv_w;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i * 64 + lane < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[i][e] - mean; sq += d * d; }
+        }
+    }
+    return (f32x2){mean, rsqrtf(wave_sum(sq) * inv_w + eps)};
+}
+
 // x * sigmoid(1.702 x) with the hardware 2^x and reciprocal (1 ulp each; the IEEE division the plain expression compiles to
 // costs 10 instructions per element, 8 % of a 256x256x1024 GEMM tile)
 __device__ __forceinline__ float quick_gelu(float x) {

@@ -35,6 +35,9 @@ int otter_gemm64_launch(int dtype, const void* A, long lda, const void* W, const
                         void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
                         const float* ln_colsum, hipStream_t s);
 
+int otter_gemm64_splitk_stats_launch(int dtype, const void* A, long lda, const void* W, const float* bias, void* x, long ldx,
+                                     int m_main, int rem, int N, int K, float* stats, float eps, float* workspace, int splits,
+                                     hipStream_t s);
 int otter_gemm64_splitk_launch(int dtype, const void* A, long lda, const void* W, const float* bias, const void* residual, long ldr,
                                void* C, long ldc, int M, int N, int K, int act, bool out_f32, bool res, const float* ln_stats,
                                const float* ln_colsum, float* workspace, int splits, hipStream_t s);
@@ -341,6 +344,33 @@ extern "C" int otter_gemm_ws(int dtype, const void* A, long lda, const void* W, 
     OTTER_REQUIRE(!row_stats || !(epilogue & OTTER_EPI_RESIDUAL), OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_ws: folded LayerNorm takes no residual");
     OTTER_REQUIRE(!workspace || (aligned16(workspace) && workspace_floats > 0), OTTER_ERR_ALIGNMENT, "otter_gemm_ws: workspace must be 16-byte aligned");
     return gemm_impl(dtype, A, lda, W, n_pad, bias, residual, ldr, C, ldc, M, N, K, epilogue, row_stats, col_sum, workspace, workspace_floats, stream);
+}
+
+// x += A W^T + bias in place on a 16-bit residual stream, and (mean, rstd) of every updated row: otter_gemm_ws with the
+// residual epilogue followed by otter_row_stats, bit for bit -- but when the < 256 remainder rows go split-K, their second
+// pass shares one launch with the statistics of all rows (one launch less per residual product).
+extern "C" int otter_gemm_residual_stats(int dtype, const void* A, long lda, const void* W, int n_pad, const float* bias, void* x,
+                                         long ldx, int M, int N, int K, float* stats, float eps, float* workspace,
+                                         long workspace_floats, void* stream) {
+    OTTER_REQUIRE(dtype == DT_BF16 || dtype == DT_F16, OTTER_ERR_INVALID_ARGUMENT, "otter_gemm_residual_stats: dtype %d (a 16-bit stream)", dtype);
+    OTTER_REQUIRE(x && stats && (reinterpret_cast<uintptr_t>(stats) & 15u) == 0, OTTER_ERR_INVALID_ARGUMENT,
+                  "otter_gemm_residual_stats: x and stats (16-byte aligned) are required");
+    OTTER_REQUIRE(!workspace || (aligned16(workspace) && workspace_floats > 0), OTTER_ERR_ALIGNMENT, "otter_gemm_residual_stats: workspace must be 16-byte aligned");
+    OTTER_REQUIRE(N > 0 && N <= 1024 && N % 8 == 0, OTTER_ERR_UNSUPPORTED_SHAPE, "otter_gemm_residual_stats: N=%d (a multiple of 8, at most 1024)", N);
+    hipStream_t s = (hipStream_t)stream;
+    const int m_main = (M / 256) * 256, rem = M - m_main;
+    const int splits = (m_main > 0 && rem > 0 && K > 0 && lda >= K && otter_gemm256_eligible(dtype, lda, n_pad, M, N, K, x, ldx))
+                           ? pick_splits(dtype, rem, N, K, workspace, workspace_floats) : 1;
+    if (splits > 1 && ldx % 8 == 0 && aligned16(x) && aligned16(A) && aligned16(W) && (!bias || aligned16(bias)) &&
+        n_pad >= ((N + BN - 1) / BN) * BN && (lda * 2) % 16 == 0) {
+        int rc = otter_gemm256_launch(dtype, A, lda, W, bias, x, ldx, x, ldx, m_main, N, K, OTTER_EPI_ACT_NONE, false, true, nullptr, nullptr, s);
+        if (rc != OTTER_OK) return rc;
+        return otter_gemm64_splitk_stats_launch(dtype, (const char*)A + (long)m_main * lda * 2, lda, W, bias, x, ldx, m_main, rem, N, K,
+                                                stats, eps, workspace, splits, s);
+    }
+    int rc = gemm_impl(dtype, A, lda, W, n_pad, bias, x, ldx, x, ldx, M, N, K, OTTER_EPI_RESIDUAL, nullptr, nullptr, workspace, workspace_floats, stream);
+    if (rc != OTTER_OK) return rc;
+    return otter_row_stats(x, dtype, ldx, stats, M, N, eps, stream);
 }
 
 // ---- allocation-free variant of otter_gemm_ws: the split-K scratch is a static device array ---------------------

@@ -357,6 +357,91 @@ __global__ __launch_bounds__(256) void splitk_reduce(ReduceArgs p) {
     }
 }
 
+// Second pass of a split-K product whose output is a 16-bit residual stream (x += A W^T + bias on the last `rem` rows of x),
+// fused with the row statistics of the WHOLE stream: the launch that would only sum the partial products of a few rows rides
+// on the one that reads every row for the LayerNorm folded into the next GEMM.  One wave per row, 8 columns per lane and
+// vector.  The first blocks take the `rem` product rows (partial sums in split order, bias, residual, rounding: the
+// arithmetic of splitk_reduce; statistics of the rounded row: the arithmetic of the row-statistics kernel), the others the
+// `m_main` rows in front of them, which the big-tile kernel has already finished.
+struct ReduceStatsArgs {
+    const float* partial; int splits;       // [splits][rem][N]
+    const float* bias;
+    void* x; long ldx;                      // the stream: rows [0, m_main + rem), 16-bit
+    float* stats;                           // [m_main + rem][2]
+    int m_main, rem, N;
+    float eps;
+};
+
+template <typename T, int SP>
+__global__ __launch_bounds__(256) void reduce_rows_stats(ReduceStatsArgs p) {
+    typedef typename Half16<T>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const int rem_blocks = (p.rem + 3) >> 2;
+    const int nvec = p.N >> 3;
+    const float inv_w = 1.0f / (float)p.N;
+    v8 v[2];
+    int row;
+    if ((int)blockIdx.x < rem_blocks) {
+        const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (r >= p.rem) return;
+        row = p.m_main + r;
+        T* xr = (T*)p.x + (long)row * p.ldx;
+        const long stride = (long)p.rem * p.N;
+        // one 4-column group at a time (its SP partial sums in flight together): the register count of this branch is the
+        // occupancy of the whole launch, and the other branch streams the stream at the memory system's rate
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = Half16<T>::from(0.f);
+            if (idx < nvec) {
+                const float* part = p.partial + (long)r * p.N + idx * 8;
+                const v8 res = *(const v8*)(xr + idx * 8);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 pv[SP];
+#pragma unroll
+                    for (int s = 0; s < SP; ++s) pv[s] = *(const f32x4*)(part + s * stride + 4 * h);
+                    f32x4 a = pv[0];
+#pragma unroll
+                    for (int s = 1; s < SP; ++s) a += pv[s];
+                    if (p.bias) a += *(const f32x4*)(p.bias + idx * 8 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][4 * h + e] = Half16<T>::from(a[e] + (float)res[4 * h + e]);
+                    asm volatile("" ::: "memory");          // keeps the next group's loads behind this one's arithmetic
+                }
+                *(v8*)(xr + idx * 8) = v[i];
+            }
+        }
+    } else {
+        row = ((int)blockIdx.x - rem_blocks) * 4 + (threadIdx.x >> 6);
+        if (row >= p.m_main) return;
+        const T* xr = (const T*)p.x + (long)row * p.ldx;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = Half16<T>::from(0.f);
+            if (idx < nvec) v[i] = *(const v8*)(xr + idx * 8);
+        }
+    }
+    const f32x2 st = row_mean_rstd_16<T>(v, lane, nvec, inv_w, p.eps);
+    if (lane == 0) *(f32x2*)(p.stats + 2 * (long)row) = st;
+}
+
+template <typename T>
+int launch_reduce_rows_stats(const ReduceStatsArgs& r, hipStream_t s) {
+    const unsigned grid = (unsigned)((r.rem + 3) / 4 + (r.m_main + 3) / 4);
+    switch (r.splits) {
+        case 2: hipLaunchKernelGGL((reduce_rows_stats<T, 2>), dim3(grid), dim3(256), 0, s, r); break;
+        case 4: hipLaunchKernelGGL((reduce_rows_stats<T, 4>), dim3(grid), dim3(256), 0, s, r); break;
+        case 8: hipLaunchKernelGGL((reduce_rows_stats<T, 8>), dim3(grid), dim3(256), 0, s, r); break;
+        default: otter_set_error("otter_gemm_residual_stats: %d splits", r.splits); return OTTER_ERR_UNSUPPORTED_SHAPE;
+    }
+    OTTER_CHECK_LAUNCH("otter_gemm_residual_stats (split-K reduce + row statistics)");
+    return OTTER_OK;
+}
+
 }  // namespace
 
 // Split-K for problems with too few 64x64 tiles to occupy the chip (the < 256 remainder rows of the tower GEMMs: 32
@@ -376,6 +461,19 @@ int otter_gemm64_splitk_launch(int dtype, const void* A, long lda, const void* W
     hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, r);
     OTTER_CHECK_LAUNCH("otter_gemm (split-K reduce)");
     return OTTER_OK;
+}
+
+// The remainder rows of an in-place 16-bit residual product (x[m_main .. m_main + rem) += A W^T + bias), split-K, with the
+// second pass fused into the row statistics of all m_main + rem rows of x (reduce_rows_stats).  A: the rem operand rows.
+int otter_gemm64_splitk_stats_launch(int dtype, const void* A, long lda, const void* W, const float* bias, void* x, long ldx,
+                                     int m_main, int rem, int N, int K, float* stats, float eps, float* workspace, int splits,
+                                     hipStream_t s) {
+    TailArgs a{(const char*)A, lda, (const char*)W, nullptr, nullptr, 0, nullptr, 0, rem, N, K, (rem + TB - 1) / TB, (N + TB - 1) / TB,
+               nullptr, nullptr, splits, workspace};
+    int rc = dtype == DT_BF16 ? launch_tail_ns<__bf16, ACT_NONE, true, false, 5>(a, s) : launch_tail_ns<_Float16, ACT_NONE, true, false, 5>(a, s);
+    if (rc != OTTER_OK) return rc;
+    ReduceStatsArgs r{workspace, splits, bias, x, ldx, stats, m_main, rem, N, eps};
+    return dtype == DT_BF16 ? launch_reduce_rows_stats<__bf16>(r, s) : launch_reduce_rows_stats<_Float16>(r, s);
 }
 
 // Shapes the 64x64 kernel accepts: 8-column vector stores and 32-bit source offsets.

@@ -139,22 +139,8 @@ __global__ __launch_bounds__(256) void row_stats16(const T* x, long ldx, float* 
     const float inv_w = 1.0f / (float)width;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += (float)v[r][i][e];
-        const float mean = wave_sum(sum) * inv_w;
-        float sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i * 64 + lane < nvec) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = (float)v[r][i][e] - mean; sq += d * d; }
-            }
-        }
-        const float rstd = rsqrtf(wave_sum(sq) * inv_w + eps);
-        if (lane == 0 && row0 + r < rows) *(f32x2*)(stats + 2 * (long)(row0 + r)) = (f32x2){mean, rstd};
+        const f32x2 st = row_mean_rstd_16<T>(v[r], lane, nvec, inv_w, eps);
+        if (lane == 0 && row0 + r < rows) *(f32x2*)(stats + 2 * (long)(row0 + r)) = st;
     }
 }
 

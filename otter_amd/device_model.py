@@ -38,6 +38,10 @@ def _f32(t: Tensor, device) -> Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+# OTTER_FUSE_STATS=0: the residual products and the row statistics behind them as separate launches (same results; A/B switch)
+_FUSE_STATS = os.environ.get("OTTER_FUSE_STATS", "1") != "0"
+
+
 class _Block:
     """One pre-LN residual attention block with packed weights (CLIP resblock or policy layer)."""
 
@@ -130,23 +134,36 @@ class ClipDevice:
     def _run_blocks(self, x: Tensor, blocks: List[_Block], n_seq: int, seq_len: int, heads: int, causal: bool,
                     stop_after_last_attention: bool) -> Tensor:
         last = None
+        # With the LayerNorms folded into in_proj / c_fc, the (mean, rstd) of the stream's rows that those GEMMs need come out
+        # of the residual product in front of them (one launch with its remainder rows' second pass); only the first block's
+        # ln_1 reads a stream nobody has just written.
+        stats = ops.row_stats(x) if (blocks and blocks[0].fold_ln) else None
         for i, b in enumerate(blocks):
+            final = i == len(blocks) - 1
             if b.fold_ln:
-                qkv = ops.gemm(x, b.wqkv, b.n_qkv, b.bqkv, ln_stats=ops.row_stats(x), ln_colsum=b.cs_qkv)
+                qkv = ops.gemm(x, b.wqkv, b.n_qkv, b.bqkv, ln_stats=stats, ln_colsum=b.cs_qkv)
             else:
                 h = ops.layernorm(x, *b.ln1, out_dtype=b.dtype)
                 qkv = ops.gemm(h, b.wqkv, b.n_qkv, b.bqkv)
             a = ops.attn_d64(qkv, n_seq, seq_len, heads, causal)
-            if stop_after_last_attention and i == len(blocks) - 1:
+            if stop_after_last_attention and final:
                 last = ops.gemm(a, b.wo, b.width, b.bo, out_f32=True)
                 break
-            ops.gemm(a, b.wo, b.width, b.bo, residual=x, out=x)
-            if b.fold_ln:
+            if b.fold_ln and _FUSE_STATS:
+                stats = ops.gemm_residual_stats_(a, b.wo, b.width, b.bo, x)
+                m = ops.gemm(x, b.w_fc, b.n_fc, b.b_fc, act=self.act, ln_stats=stats, ln_colsum=b.cs_fc)
+            elif b.fold_ln:
+                ops.gemm(a, b.wo, b.width, b.bo, residual=x, out=x)
                 m = ops.gemm(x, b.w_fc, b.n_fc, b.b_fc, act=self.act, ln_stats=ops.row_stats(x), ln_colsum=b.cs_fc)
             else:
+                ops.gemm(a, b.wo, b.width, b.bo, residual=x, out=x)
                 h = ops.layernorm(x, *b.ln2, out_dtype=b.dtype)
                 m = ops.gemm(h, b.w_fc, b.n_fc, b.b_fc, act=self.act)
-            ops.gemm(m, b.w_proj, b.width, b.b_proj, residual=x, out=x)
+            if b.fold_ln and _FUSE_STATS and not final and blocks[i + 1].fold_ln:
+                stats = ops.gemm_residual_stats_(m, b.w_proj, b.width, b.b_proj, x)
+            else:
+                ops.gemm(m, b.w_proj, b.width, b.b_proj, residual=x, out=x)
+                stats = ops.row_stats(x) if (not final and blocks[i + 1].fold_ln) else None
             if self.debug_stream:
                 self.stream_absmax.append(float(x.abs().max()))
         return last if stop_after_last_attention else x

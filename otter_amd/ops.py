@@ -215,6 +215,34 @@ def row_stats(x: Tensor, eps: float = 1e-5) -> Tensor:
     return stats
 
 
+def gemm_residual_stats_(a: Tensor, w_packed: Tensor, n: int, bias: Optional[Tensor], x: Tensor, eps: float = 1e-5) -> Tensor:
+    """x[M, n] += a[M, K] @ w[n, K]^T + bias in place on the 16-bit residual stream ``x``; returns the (M, 2) fp32 row
+    statistics (mean, 1/sqrt(var + eps)) of the updated rows.  The same results as ``gemm(a, w, n, bias, residual=x, out=x)``
+    followed by ``row_stats(x)``, with one launch less when the remainder rows of a big problem go split-K."""
+    dt = _dt(a.dtype, "gemm_residual_stats.a", False)
+    _chk(a, a.dtype, "gemm_residual_stats.a")
+    _chk(w_packed, a.dtype, "gemm_residual_stats.w", 2)
+    _chk(x, a.dtype, "gemm_residual_stats.x")
+    m, k, lda = _rows_view(a, "gemm_residual_stats.a")
+    mx, nx, ldx = _rows_view(x, "gemm_residual_stats.x")
+    if not w_packed.is_contiguous() or w_packed.shape[1] != k or w_packed.shape[0] < round_up(n, GEMM_N_ALIGN):
+        raise ValueError(f"gemm_residual_stats: weight {tuple(w_packed.shape)} does not match K={k}, N={n}")
+    if mx != m or nx != n:
+        raise ValueError(f"gemm_residual_stats: x is {tuple(x.shape)}, expected ({m}, {n})")
+    if bias is not None:
+        _chk(bias, torch.float32, "gemm_residual_stats.bias", 1)
+        if bias.numel() < n:
+            raise ValueError("gemm_residual_stats: bias shorter than N")
+    stats = torch.empty(m, 2, dtype=torch.float32, device=x.device)
+    if m == 0:
+        return stats
+    ws, lock = _gemm_workspace(a.device, n) if (_SPLIT_K and (m % 256 != 0 or m < 1024)) else (None, None)
+    with lock if lock is not None else contextlib.nullcontext():
+        _lib.call("otter_gemm_residual_stats", dt, _ptr(a), lda, _ptr(w_packed), w_packed.shape[0], _ptr(bias), _ptr(x), ldx,
+                  m, n, k, _ptr(stats), eps, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+    return stats
+
+
 def fold_layernorm(weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, dtype, device=None):
     """Fold ``LayerNorm(gamma, beta)`` into the Linear that follows it: (packed W * gamma in ``dtype``, bias + W . beta,
     column sums of the ROUNDED W * gamma) -- the operands of ``gemm(..., ln_stats=row_stats(x), ln_colsum=...)``."""

@@ -13,7 +13,7 @@ row of the K/V cache, a slice of the concatenated feature buffer, the rollout wi
 
 | operator | reference arithmetic |
 |---|---|
-| ``gemm``, ``gemm_into``, ``gemm_residual_`` | every ``nn.Linear`` / ``conv1`` of the path; bias, activation, residual add and a LayerNorm folded into the weights are epilogues |
+| ``gemm``, ``gemm_into``, ``gemm_residual_``, ``gemm_residual_stats_`` | every ``nn.Linear`` / ``conv1`` of the path; bias, activation, residual add and a LayerNorm folded into the weights are epilogues |
 | ``row_stats`` | mean / rstd of ``ln_1`` / ``ln_2`` rows for the folded LayerNorm |
 | ``layernorm`` | ``LayerNorm`` |
 | ``im2col_patches`` | ``clip_transform`` + patch extraction for ``visual.conv1`` (``vision_tf.py:28-52``) |
@@ -47,6 +47,7 @@ _SCHEMAS = (
     "gemm(Tensor a, Tensor w_packed, int n, Tensor? bias, int act, bool out_f32, Tensor? residual, Tensor? ln_stats=None, Tensor? ln_colsum=None) -> Tensor",
     "gemm_into(Tensor(a!) out, Tensor a, Tensor w_packed, int n, Tensor? bias, int act, Tensor? residual, Tensor? ln_stats=None, Tensor? ln_colsum=None) -> ()",
     "gemm_residual_(Tensor(a!) x, Tensor a, Tensor w_packed, int n, Tensor? bias) -> ()",
+    "gemm_residual_stats_(Tensor(a!) x, Tensor a, Tensor w_packed, int n, Tensor? bias, float eps) -> Tensor",
     "row_stats(Tensor x, float eps) -> Tensor",
     "layernorm(Tensor x, Tensor? gamma, Tensor? beta, float eps, int out_dtype) -> Tensor",
     "im2col_patches(Tensor images, int patch, int kpad, float[] mean, float[] std, int out_dtype) -> Tensor",
@@ -94,6 +95,10 @@ def _gemm_into(out, a, w_packed, n, bias, act, residual, ln_stats=None, ln_colsu
 
 def _gemm_residual_(x, a, w_packed, n, bias):
     ops.gemm(a, w_packed, n, bias, residual=x, out=x)
+
+
+def _gemm_residual_stats_(x, a, w_packed, n, bias, eps):
+    return ops.gemm_residual_stats_(a, w_packed, n, bias, x, eps)
 
 
 def _row_stats(x, eps):
@@ -209,6 +214,11 @@ def _(out, a, w_packed, n, bias, act, residual, ln_stats=None, ln_colsum=None):
 @_fake("gemm_residual_")
 def _(x, a, w_packed, n, bias):
     return None
+
+
+@_fake("gemm_residual_stats_")
+def _(x, a, w_packed, n, bias, eps):
+    return x.new_empty((x.shape[0], 2), dtype=torch.float32)
 
 
 @_fake("row_stats")
@@ -345,6 +355,9 @@ class _Namespace:
         else:
             self._op["gemm_into"](out, a, w_packed, n, bias, act, residual, ln_stats, ln_colsum)
         return out
+
+    def gemm_residual_stats_(self, a, w_packed, n, bias, x, eps=1e-5):
+        return self._op["gemm_residual_stats_"](x, a, w_packed, n, bias, eps)
 
     def row_stats(self, x, eps=1e-5):
         return self._op["row_stats"](x, eps)

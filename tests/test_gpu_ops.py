@@ -246,6 +246,35 @@ def test_gemm_split_k_matches_one_pass(dev, m, n, k, dtype):
     assert lib.otter_gemm_workspace_floats(n) >= 8 * 255 * n
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("m,n,k", [(32896, 1024, 1024),      # out_proj of a 128-image step: 128 big row tiles + 128 split-K remainder rows
+                                   (32896 + 64, 1024, 4096),  # c_proj: K = 4096, 192 remainder rows
+                                   (33024, 768, 1024),        # whole tiles only
+                                   (514, 1024, 1024),         # a single observation: no big tiles
+                                   (32896, 264, 512)])        # a width that leaves the second vector of most lanes empty
+def test_gemm_residual_stats_matches_the_two_launches(dev, dtype, m, n, k):
+    """x += a W^T + bias and the row statistics of the result from one entry point: bit for bit the residual product followed by
+    otter_row_stats, whether the remainder rows' second pass is fused with the statistics or not."""
+    from otter_amd import ops
+    dt = DTYPES[dtype]
+    a = (_randn(40, m, k) * 0.5).to(dev).to(dt)
+    wp = ops.pack_weight(_randn(41, n, k).to(dev) / math.sqrt(k), dt)
+    bias = _randn(42, n).to(dev)
+    x0 = (_randn(43, m, n) * 3).to(dev).to(dt)
+    x0[:, 5] *= 40.0                                   # an outlier channel, as the real streams have
+    want = ops.gemm(a, wp, n, bias, residual=x0.clone())
+    want_stats = ops.row_stats(want)
+    x = x0.clone()
+    stats = ops.gemm_residual_stats_(a, wp, n, bias, x)
+    assert torch.equal(x, want)
+    assert torch.equal(stats, want_stats)
+    # and in a row-strided view of a wider stream
+    wide = torch.zeros(m, n + 16, dtype=dt, device=dev)
+    wide[:, :n] = x0
+    stats2 = ops.gemm_residual_stats_(a, wp, n, bias, wide[:, :n])
+    assert torch.equal(wide[:, :n], want) and torch.equal(stats2, want_stats) and torch.all(wide[:, n:] == 0)
+
+
 @pytest.mark.parametrize("m", [777, 1300])          # 128-row tiles only / 256-row tiles plus a 128-row-tile remainder
 def test_gemm_residual_strided_inplace(dev, m):
     from otter_amd import ops
@@ -638,6 +667,10 @@ def test_torch_custom_ops_match_the_wrappers(dev):
     x_res = res.clone()
     op("gemm_residual_")(x_res, a, wp, 248, bias)
     assert torch.equal(x_res, ops.gemm(a, wp, 248, bias, residual=res))
+    x16 = res.to(dt)
+    want16 = ops.gemm(a, wp, 248, bias, residual=x16)
+    st16 = op("gemm_residual_stats_")(x16, a, wp, 248, bias, 1e-5)
+    assert torch.equal(x16, want16) and torch.equal(st16, ops.row_stats(want16))
     x = _randn(95, 37, 768).to(dev)
     g, b = _randn(96, 768).to(dev), _randn(97, 768).to(dev)
     assert torch.equal(op("layernorm")(x, g, b, 1e-5, 1), ops.layernorm(x, g, b, out_dtype=dt))
@@ -747,7 +780,7 @@ def test_encoder_traces_into_one_graph_of_custom_operators(dev):
     kernels_in_graph = [t for t in targets if t.startswith("otter_hip.")]
     names = {t.split(".")[1] for t in kernels_in_graph}
     print(f"encode(): one FX graph, {len(kernels_in_graph)} otter_hip kernel nodes of {len(targets)} calls; operators {sorted(names)}")
-    assert {"im2col_patches", "gemm", "gemm_residual_", "row_stats", "attn_fwd_d64", "vit_embed_lnpre", "layernorm", "text_aware_pool",
+    assert {"im2col_patches", "gemm", "gemm_residual_stats_", "row_stats", "attn_fwd_d64", "vit_embed_lnpre", "layernorm", "text_aware_pool",
             "readout_pool_multi", "l2norm_rows", "linear_f32", "linear_f32_into"} <= names
     assert len(kernels_in_graph) > 20
     assert torch.equal(got, eager)

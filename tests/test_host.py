@@ -446,7 +446,7 @@ def test_torch_custom_ops_are_registered_and_have_no_cpu_implementation():
     of them, and a loud failure on CPU tensors."""
     import otter_amd.torch_ops as T
     ns = torch.ops.otter_hip
-    assert len(T.OP_NAMES) == 23
+    assert len(T.OP_NAMES) == 24
     for name in T.OP_NAMES:
         assert hasattr(ns, name), name
     f16, f32, i32, u8, f64 = torch.float16, torch.float32, torch.int32, torch.uint8, torch.float64
@@ -459,6 +459,7 @@ def test_torch_custom_ops_are_registered_and_have_no_cpu_implementation():
     assert tuple(y.shape) == (300, 256) and y.dtype == f16
     assert ns.gemm_into(meta(300, 256), meta(300, 128), meta(256, 128), 256, None, 0, None) is None
     assert ns.gemm_residual_(meta(300, 256), meta(300, 128), meta(256, 128), 256, None) is None
+    assert tuple(ns.gemm_residual_stats_(meta(300, 256), meta(300, 128), meta(256, 128), 256, None, 1e-5).shape) == (300, 2)
     assert tuple(ns.row_stats(meta(300, 128), 1e-5).shape) == (300, 2)
     assert ns.layernorm(meta(7, 64, dtype=f32), None, None, 1e-5, 0).dtype == torch.bfloat16
     y = ns.im2col_patches(meta(4, 3, 224, 224, dtype=u8), 14, 640, [0.5, 0.5, 0.5], [0.2, 0.2, 0.2], 1)

@@ -304,8 +304,9 @@ def test_openclip_gelu_backbone_text_aware_extraction(dev):
     assert _cos(got_tf[:, 15], tf16[:, 15]) >= 0.9999                      # the pooled row on its own
     err = (small.cpu() - ref).abs().max().item()
     print(f"OpenCLIP-variant extraction: cosine {_cos(small.cpu(), ref):.6f}, max abs err {err:.2e} (|ref| max {ref.abs().max():.2f})")
-    # temperature 0.005 turns a 1e-4 error of a cosine into 2 % of a softmax weight: see the kernel-level test
-    assert _cos(small.cpu(), ref) >= 0.9999 and err <= 2e-2
+    # temperature 0.005 turns a 1e-4 error of a cosine into 2 % of a softmax weight (see the kernel-level test); measured
+    # 4.8e-4 on this case, bound = four times that
+    assert _cos(small.cpu(), ref) >= 0.9999 and err <= 2e-3
     big, _ = extract(n_big)
     # batch-size independent up to summation order: which rows of a GEMM are multiplied split-K depends on the row count
     torch.testing.assert_close(big[:n_small], small, rtol=0, atol=2e-3)

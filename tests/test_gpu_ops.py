@@ -441,8 +441,9 @@ def test_text_aware_pool(dev, n_obs, cams, P, D, K, t_rep, temperature, dtype):
     for c in range(cams):
         ref = R.text_aware_visual_extraction(pf[:, c].cpu(), tf.cpu(), torch.tensor(temperature), pos[c].cpu()).to(dev)
         # 16-bit rounding of text tokens, softmax weights and pos_emb: ~2^-8 (bf16) / 2^-11 (fp16) relative to
-        # |pos_emb| <= 1.1; the logit error from the rounded text tokens is amplified by 1/temperature (200x at 0.005)
-        tol = (4e-2 if temperature < 0.01 else 1e-2) if dtype == "bf16" else (5e-3 if temperature < 0.01 else 1.5e-3)
+        # |pos_emb| <= 1.1; the logit error from the rounded text tokens is amplified by 1/temperature (200x at 0.005).
+        # Bounds = twice the worst error measured over these cases (bf16: 2.5e-2 at 0.005, 1.7e-3 otherwise; fp16: 2.5e-3, 3.0e-4)
+        tol = (4e-2 if temperature < 0.01 else 3.5e-3) if dtype == "bf16" else (5e-3 if temperature < 0.01 else 6e-4)
         torch.testing.assert_close(out[c], ref, rtol=tol, atol=tol)
 
 

@@ -280,6 +280,25 @@ struct PolicyAttnArgs {
     float scale;
 };
 
+// q . k over hd floats (hd % 4 == 0) with eight 16-byte loads of each row in flight at a time: a loop with a run-time bound
+// that loads, waits and multiplies once per 16 bytes spends one memory round trip per iteration (24 of them at hd = 96).
+__device__ __forceinline__ float dot_rows(const float* a, const float* b, int hd) {
+    float acc = 0.f;
+    int d = 0;
+    for (; d + 32 <= hd; d += 32) {
+        f32x4 av[8], bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { av[i] = *(const f32x4*)(a + d + 4 * i); bv[i] = *(const f32x4*)(b + d + 4 * i); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += av[i][0] * bv[i][0] + av[i][1] * bv[i][1] + av[i][2] * bv[i][2] + av[i][3] * bv[i][3];
+    }
+    for (; d < hd; d += 4) {
+        const f32x4 av = *(const f32x4*)(a + d), bv = *(const f32x4*)(b + d);
+        acc += av[0] * bv[0] + av[1] * bv[1] + av[2] * bv[2] + av[3] * bv[3];
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void attn_policy(PolicyAttnArgs p, int total) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -291,22 +310,24 @@ __global__ __launch_bounds__(256) void attn_policy(PolicyAttnArgs p, int total) 
     float sc = -INFINITY;
     if (lane < nkeys) {
         const float* krow = p.qkv + ((long)b * p.S + lane) * p.ld + dim + h * p.hd;
-        float acc = 0.f;
-        for (int d = 0; d < p.hd; d += 4) {
-            const f32x4 a = *(const f32x4*)(qrow + d), k = *(const f32x4*)(krow + d);
-            acc += a[0] * k[0] + a[1] * k[1] + a[2] * k[2] + a[3] * k[3];
-        }
-        sc = acc * p.scale;
+        sc = dot_rows(qrow, krow, p.hd) * p.scale;
     }
     const float mx = wave_max(sc);
     const float e = (lane < nkeys) ? __expf(sc - mx) : 0.f;
     const float inv = 1.0f / wave_sum(e);
+    // four value rows in flight per pass (same summation order as one at a time)
+    const float* vbase = p.qkv + (long)b * p.S * p.ld + 2 * dim + h * p.hd;
     for (int d = lane; d < p.hd; d += 64) {
         float acc = 0.f;
-        for (int j = 0; j < nkeys; ++j) {
-            const float pj = __shfl(e, j, 64);
-            acc += pj * p.qkv[((long)b * p.S + j) * p.ld + 2 * dim + h * p.hd + d];
+        int j = 0;
+        for (; j + 4 <= nkeys; j += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = vbase[(long)(j + u) * p.ld + d];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += __shfl(e, j + u, 64) * v[u];
         }
+        for (; j < nkeys; ++j) acc += __shfl(e, j, 64) * vbase[(long)j * p.ld + d];
         p.out[((long)b * p.Tq + i) * p.ldo + h * p.hd + d] = acc * inv;
     }
 }
@@ -349,22 +370,23 @@ __global__ __launch_bounds__(256) void attn_policy_rows(PolicyRowsArgs p, int to
     float sc = -INFINITY;
     if (lane < nkeys) {
         const float* krow = (lane == pos) ? knew : hist + (long)lane * p.ld + dim + h * p.hd;
-        float acc = 0.f;
-        for (int d = 0; d < p.hd; d += 4) {
-            const f32x4 a = *(const f32x4*)(qrow + d), k = *(const f32x4*)(krow + d);
-            acc += a[0] * k[0] + a[1] * k[1] + a[2] * k[2] + a[3] * k[3];
-        }
-        sc = acc * p.scale;
+        sc = dot_rows(qrow, krow, p.hd) * p.scale;
     }
     const float mx = wave_max(sc);
     const float ex = (lane < nkeys) ? __expf(sc - mx) : 0.f;
     const float inv = 1.0f / wave_sum(ex);
+    const float* vhist = hist + 2 * dim + h * p.hd;
     for (int d = lane; d < p.hd; d += 64) {
         float acc = 0.f;
-        for (int j = 0; j < nkeys; ++j) {
-            const float pj = __shfl(ex, j, 64);
-            acc += pj * (j == pos ? vnew[d] : hist[(long)j * p.ld + 2 * dim + h * p.hd + d]);
+        int j = 0;
+        for (; j + 4 <= nkeys; j += 4) {                       // four value rows in flight per pass
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (j + u == pos) ? vnew[d] : vhist[(long)(j + u) * p.ld + d];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += __shfl(ex, j + u, 64) * v[u];
         }
+        for (; j < nkeys; ++j) acc += __shfl(ex, j, 64) * (j == pos ? vnew[d] : vhist[(long)j * p.ld + d]);
         p.out[(long)i * p.ldo + h * p.hd + d] = acc * inv;
     }
 }

@@ -163,15 +163,32 @@ __device__ __forceinline__ void tile_pv(const char* sV, const f32x4 (&s)[NQ][NT]
 }
 
 // (a convex combination of 16-bit values: no saturation needed on the way back to 16 bits)
+// Lane (g, li) holds columns dt*16 + 4g .. + 3 of its query's row for the four d-tiles: 8-byte pieces, four lanes and four
+// store instructions per 128-byte row, every instruction writing 32-byte fragments of 16 different lines.  One
+// v_permlane16_swap per packed register pairs the pieces of neighbouring lane groups instead: lane groups 0 / 2 end up with
+// 8 consecutive columns of an even d-tile, groups 1 / 3 with 8 consecutive columns of the odd d-tile next to it, so a row
+// leaves in two instructions of 64 contiguous bytes (16 bytes per lane).  `valid`: the lane's query exists (the exchange
+// itself needs every lane).
 template <typename T>
-__device__ __forceinline__ void tile_store(T* row_out, const f32x4 (&o)[4], float inv, int g) {
-    typedef typename Half16<T>::v4 v4;
+__device__ __forceinline__ void tile_store(T* row_out, const f32x4 (&o)[4], float inv, int g, bool valid) {
+    typedef typename Half16<T>::v8 v8;
+    union { typename Half16<T>::v4 h; unsigned w[2]; } pk[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        v4 ob;
+    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ob[r] = (T)(o[dt][r] * inv);
-        *(v4*)(row_out + dt * 16 + g * 4) = ob;
+        for (int r = 0; r < 4; ++r) pk[dt].h[r] = (T)(o[dt][r] * inv);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        union { unsigned w[4]; v8 v; } out;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            // rows of 16 lanes = lane groups: group 2k+1 of the first operand trades places with group 2k of the second
+            const auto sw = __builtin_amdgcn_permlane16_swap(pk[2 * pr].w[w], pk[2 * pr + 1].w[w], false, false);
+            out.w[w] = sw[0];            // even group: its own even-tile piece      odd group: the even group's odd-tile piece
+            out.w[2 + w] = sw[1];        // even group: the odd group's even-tile piece   odd group: its own odd-tile piece
+        }
+        const int col = (g & 1) ? (2 * pr + 1) * 16 + 4 * (g - 1) : 2 * pr * 16 + 4 * g;
+        if (valid) *(v8*)(row_out + col) = out.v;
     }
 }
 
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, NT <= 18 ? 2 : 1) void attn_d64(AttnArgs p
 #pragma unroll
         for (int t = 0; t < NQ; ++t) {
             const int q = (qt + t * NW) * 16 + li;
-            if (q < L) tile_store<T>(outp + (row0 + q) * p.ldo + h * 64, o[t], inv[t], g);
+            tile_store<T>(outp + (row0 + min(q, L - 1)) * p.ldo + h * 64, o[t], inv[t], g, q < L);
         }
     };
     int qt = wslot;
